@@ -1,0 +1,927 @@
+// libdfx: gfx950 (MI355X, CDNA4) kernels for the FusionCG / FusionAdam / baseline() hot path.
+// C ABI in include/dfx.h.  Everything here is HBM-bandwidth-bound fp32 streaming + reductions:
+// no MFMA.  The 5-D vectors x, r, p (layout (t, l, z, x, y), y contiguous) are swept by
+// workgroups of four 64-lane waves; each wave owns a "wave tile" of 4 rows x 64 columns
+// (one row of sixteen 4x4 downsampling blocks), each lane a float4 (one block row), for `zc`
+// z-planes held in registers and a chunk of `steps` consecutive (t,l) slabs:
+//   * u = sum_{t,l} (fusion.py:44-51, T and S) accumulates in zc float4 registers per lane and is
+//     written once per workgroup to u_part[chunk];
+//   * v = sum_z sum_{4x4} (fusion.py:44-51 D, fusion.py:89-98 R) is a lane-local sum over z and
+//     the float4, then two cross-lane adds (lanes l, l^16, l^32, l^48 hold the 4 rows of a block).
+// No LDS tile and no barrier in the streaming loop; LDS is only used for the per-workgroup
+// scalar partials.  Shapes that do not fit (r != 4 or Y % 64 != 0) take the generic kernels.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dfx.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+int hipfail(hipError_t e, const char *where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return (int)e;
+}
+#define DFX_LAUNCH_CHECK(where)                         \
+    do {                                                \
+        hipError_t e_ = hipGetLastError();              \
+        if (e_ != hipSuccess) return hipfail(e_, where); \
+    } while (0)
+
+struct Geo {
+    long long S;   // elements per (t,l) slab = nZ*X*Y
+    long long P;   // elements per plane = X*Y
+    long long Ps;  // Xs*Ys
+    long long N;   // M*S
+    int M;         // nT*nL
+    int nZ, X, Y, Xs, Ys, r;
+    int WT;        // wave tiles per plane (fast path)
+    int tiles_y;   // Y/64
+};
+
+int make_geo(const dfx_geom *g, Geo *o) {
+    if (!g) return fail(DFX_EINVAL, "geom is NULL");
+    if (g->nT <= 0 || g->nL <= 0 || g->nZ <= 0 || g->X <= 0 || g->Y <= 0 || g->r <= 0)
+        return fail(DFX_EINVAL, "geom extents must be positive");
+    if (g->X % g->r || g->Y % g->r) return fail(DFX_EINVAL, "X and Y must be multiples of r");
+    long long M = g->nT * g->nL;
+    if (M > 0x7fffffffLL || g->nZ > 0x7fffffffLL || g->X > 0x7fffffffLL || g->Y > 0x7fffffffLL)
+        return fail(DFX_EINVAL, "extent too large");
+    o->M = (int)M;
+    o->nZ = (int)g->nZ;
+    o->X = (int)g->X;
+    o->Y = (int)g->Y;
+    o->r = g->r;
+    o->Xs = o->X / o->r;
+    o->Ys = o->Y / o->r;
+    o->P = (long long)o->X * o->Y;
+    o->Ps = (long long)o->Xs * o->Ys;
+    o->S = o->P * o->nZ;
+    o->N = o->S * M;
+    if (o->S > 0x7fffffffLL) return fail(DFX_EINVAL, "one (t,l) slab must stay below 2^31 elements");
+    o->tiles_y = o->Y / 64;
+    o->WT = (o->X / 4) * (o->Y / 64);
+    return 0;
+}
+
+bool fast_ok(const Geo &q) { return q.r == 4 && q.Y % 64 == 0; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Per-workgroup partials (a, b, c) -> row[0..2] (row[3] = 0).  Fixed order: deterministic.
+__device__ __forceinline__ void block_store3(double a, double b, double c, double *row) {
+    __shared__ double sh[16][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    if (lane == 0) {
+        sh[wave][0] = a;
+        sh[wave][1] = b;
+        sh[wave][2] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int w = 0; w < nw; ++w) {
+            s0 += sh[w][0];
+            s1 += sh[w][1];
+            s2 += sh[w][2];
+        }
+        row[0] = s0;
+        row[1] = s1;
+        row[2] = s2;
+        row[3] = 0.0;
+    }
+}
+
+__device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+__device__ __forceinline__ f4 ld4s(const float *p) {  // streamed once: non-temporal
+    return __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+}
+__device__ __forceinline__ void st4s(float *p, f4 v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+}
+__device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float dot4(f4 a, f4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+// ------------------------------------------------------------------------------------------
+// Fast sweep: x += alpha p ; p = r + beta p ; u(p), v(p), ||p||^2, ||x||^2, <x,p>   (MODE XP)
+// ------------------------------------------------------------------------------------------
+struct SweepArgs {
+    float *x;
+    const float *r;
+    float *p;
+    const double *scal;
+    float *u_part;
+    float *v_part;
+    double *part;
+    Geo q;
+    int steps;
+};
+
+template <int MODE, int ZC, bool FULL>
+__device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0, int m1, long long off,
+                                            long long voff, float fa, float fb, f4 (&uacc)[ZC], double &dpp,
+                                            double &dxx, double &dxp) {
+    const int lane = threadIdx.x & 63;
+    constexpr int ZB = ZC < 4 ? ZC : 4;
+    for (int m = m0; m < m1; ++m) {
+        const long long base = (long long)m * a.q.S + off;
+        f4 s4 = {0.f, 0.f, 0.f, 0.f};
+        float pp = 0.f, xx = 0.f, xp = 0.f;
+#pragma unroll
+        for (int g = 0; g < ZC; g += ZB) {
+            f4 xv[ZB], rv[ZB], pv[ZB];
+#pragma unroll
+            for (int j = 0; j < ZB; ++j) {
+                if (FULL || g + j < zcnt) {
+                    const long long i = base + (long long)(g + j) * a.q.P;
+                    if (MODE == DFX_SWEEP_PROJECT) {
+                        xv[j] = ld4s(a.x + i);
+                    } else if (MODE == DFX_SWEEP_XP) {
+                        xv[j] = ld4s(a.x + i);
+                        rv[j] = ld4s(a.r + i);
+                        pv[j] = ld4s(a.p + i);
+                    } else if (MODE == DFX_SWEEP_P) {
+                        rv[j] = ld4s(a.r + i);
+                        pv[j] = ld4s(a.p + i);
+                    } else {  // PINIT
+                        xv[j] = ld4s(a.x + i);
+                        rv[j] = ld4s(a.r + i);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ZB; ++j) {
+                if (FULL || g + j < zcnt) {
+                    const long long i = base + (long long)(g + j) * a.q.P;
+                    f4 pn;
+                    if (MODE == DFX_SWEEP_PROJECT) {
+                        pn = xv[j];
+                        xx += dot4(pn, pn);
+                    } else if (MODE == DFX_SWEEP_XP) {
+                        const f4 xn = xv[j] + fa * pv[j];
+                        pn = rv[j] + fb * pv[j];
+                        st4s(a.x + i, xn);
+                        st4s(a.p + i, pn);
+                        xx += dot4(xn, xn);
+                        xp += dot4(xn, pn);
+                        pp += dot4(pn, pn);
+                    } else if (MODE == DFX_SWEEP_P) {
+                        pn = rv[j] + fb * pv[j];
+                        st4s(a.p + i, pn);
+                        pp += dot4(pn, pn);
+                    } else {
+                        pn = rv[j];
+                        st4s(a.p + i, pn);
+                        xx += dot4(xv[j], xv[j]);
+                        xp += dot4(xv[j], pn);
+                        pp += dot4(pn, pn);
+                    }
+                    uacc[g + j] += pn;
+                    s4 += pn;
+                }
+            }
+        }
+        // 4x4 block sum: the lane's float4 is one block row; rows live in lanes l, l^16, l^32, l^48
+        float s = hsum(s4);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lane < 16) a.v_part[voff + (long long)m * a.q.Ps] = s;
+        dpp += (double)pp;
+        dxx += (double)xx;
+        dxp += (double)xp;
+    }
+}
+
+template <int MODE, int ZC>
+__global__ __launch_bounds__(256) void k_sweep_fast(const SweepArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = blockIdx.x * 4 + wave;
+    const int z0 = blockIdx.y * ZC;
+    const int zcnt = min(ZC, a.q.nZ - z0);
+    const int m0 = blockIdx.z * a.steps;
+    const int m1 = min(m0 + a.steps, a.q.M);
+    double dpp = 0, dxx = 0, dxp = 0;
+    if (wt < a.q.WT) {  // wave-uniform
+        const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
+        const int row = tx * 4 + (lane >> 4);
+        const int col = ty * 64 + (lane & 15) * 4;
+        const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
+        const long long voff =
+            (long long)blockIdx.y * a.q.M * a.q.Ps + (long long)tx * a.q.Ys + ty * 16 + (lane & 15);
+        const float fa = (MODE == DFX_SWEEP_XP) ? (float)a.scal[DFX_S_ALPHA] : 0.f;
+        const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)a.scal[DFX_S_BETA] : 0.f;
+        f4 uacc[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (zcnt == ZC)
+            sweep_steps<MODE, ZC, true>(a, zcnt, m0, m1, off, voff, fa, fb, uacc, dpp, dxx, dxp);
+        else
+            sweep_steps<MODE, ZC, false>(a, zcnt, m0, m1, off, voff, fa, fb, uacc, dpp, dxx, dxp);
+        float *up = a.u_part + (long long)blockIdx.z * a.q.S + off;
+#pragma unroll
+        for (int k = 0; k < ZC; ++k)
+            if (k < zcnt) st4(up + (long long)k * a.q.P, uacc[k]);
+    }
+    const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_store3(dpp, dxx, dxp, a.part + bid * DFX_NPART);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast broadcast-axpy: out = in + coef*mask*(sa*A[z,x,y] + sb*B[m,x/4,y/4]); sum(out^2)
+// ------------------------------------------------------------------------------------------
+struct BcastArgs {
+    float *out;
+    const float *in;
+    const float *A;
+    const float *B;
+    const float *mask;
+    const double *coef_dev;
+    double *part;
+    float sa, sb, coef_host;
+    Geo q;
+    int steps;
+};
+
+template <int ZC, bool HAS_IN, bool HAS_MASK, bool FULL>
+__device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0, int m1, long long off,
+                                            long long boff, float cb, const f4 (&av)[ZC], const f4 (&mk)[ZC],
+                                            double &drr) {
+    constexpr int ZB = ZC < 4 ? ZC : 4;
+    for (int m = m0; m < m1; ++m) {
+        const long long base = (long long)m * a.q.S + off;
+        const float b = cb * a.B[boff + (long long)m * a.q.Ps];
+        float rr = 0.f;
+#pragma unroll
+        for (int g = 0; g < ZC; g += ZB) {
+            f4 iv[ZB];
+            if (HAS_IN) {
+#pragma unroll
+                for (int j = 0; j < ZB; ++j)
+                    if (FULL || g + j < zcnt) iv[j] = ld4s(a.in + base + (long long)(g + j) * a.q.P);
+            }
+#pragma unroll
+            for (int j = 0; j < ZB; ++j) {
+                if (FULL || g + j < zcnt) {
+                    f4 o = av[g + j] + (HAS_MASK ? mk[g + j] * b : (f4){b, b, b, b});
+                    if (HAS_IN) o += iv[j];
+                    st4s(a.out + base + (long long)(g + j) * a.q.P, o);
+                    rr += dot4(o, o);
+                }
+            }
+        }
+        drr += (double)rr;
+    }
+}
+
+template <int ZC, bool HAS_IN, bool HAS_MASK>
+__global__ __launch_bounds__(256) void k_bcast_fast(const BcastArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = blockIdx.x * 4 + wave;
+    const int z0 = blockIdx.y * ZC;
+    const int zcnt = min(ZC, a.q.nZ - z0);
+    const int m0 = blockIdx.z * a.steps;
+    const int m1 = min(m0 + a.steps, a.q.M);
+    double drr = 0;
+    if (wt < a.q.WT) {
+        const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
+        const int row = tx * 4 + (lane >> 4);
+        const int col = ty * 64 + (lane & 15) * 4;
+        const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
+        const long long boff = (long long)tx * a.q.Ys + ty * 16 + (lane & 15);
+        const float coef = a.coef_host * (a.coef_dev ? (float)(*a.coef_dev) : 1.f);
+        const float ca = coef * a.sa, cb = coef * a.sb;
+        f4 av[ZC], mk[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) {
+            av[k] = (f4){0.f, 0.f, 0.f, 0.f};
+            mk[k] = (f4){1.f, 1.f, 1.f, 1.f};
+            if (k < zcnt) {
+                av[k] = ca * ld4(a.A + off + (long long)k * a.q.P);
+                if (HAS_MASK) {
+                    mk[k] = ld4(a.mask + off + (long long)k * a.q.P);
+                    av[k] *= mk[k];
+                }
+            }
+        }
+        if (zcnt == ZC)
+            bcast_steps<ZC, HAS_IN, HAS_MASK, true>(a, zcnt, m0, m1, off, boff, cb, av, mk, drr);
+        else
+            bcast_steps<ZC, HAS_IN, HAS_MASK, false>(a, zcnt, m0, m1, off, boff, cb, av, mk, drr);
+    }
+    const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_store3(drr, 0.0, 0.0, a.part + bid * DFX_NPART);
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic (any r, X, Y) kernels: element-wise pass + two projection passes.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gen_sweep(float *x, const float *r, float *p, const double *scal,
+                                                   long long n, double *part) {
+    const float fa = (MODE == DFX_SWEEP_XP) ? (float)scal[DFX_S_ALPHA] : 0.f;
+    const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)scal[DFX_S_BETA] : 0.f;
+    double dpp = 0, dxx = 0, dxp = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (MODE == DFX_SWEEP_PROJECT) {
+            const float xv = x[i];
+            dxx += (double)(xv * xv);
+        } else if (MODE == DFX_SWEEP_XP) {
+            const float pv = p[i];
+            const float xn = x[i] + fa * pv;
+            const float pn = r[i] + fb * pv;
+            x[i] = xn;
+            p[i] = pn;
+            dxx += (double)(xn * xn);
+            dxp += (double)(xn * pn);
+            dpp += (double)(pn * pn);
+        } else if (MODE == DFX_SWEEP_P) {
+            const float pn = r[i] + fb * p[i];
+            p[i] = pn;
+            dpp += (double)(pn * pn);
+        } else {
+            const float xv = x[i], pn = r[i];
+            p[i] = pn;
+            dxx += (double)(xv * xv);
+            dxp += (double)(xv * pn);
+            dpp += (double)(pn * pn);
+        }
+    }
+    block_store3(dpp, dxx, dxp, part + (long long)blockIdx.x * DFX_NPART);
+}
+
+__global__ __launch_bounds__(256) void k_gen_proj_u(const float *a, float *u, Geo q) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < q.S; j += stride) {
+        float s = 0.f;
+        for (int m = 0; m < q.M; ++m) s += a[(long long)m * q.S + j];
+        u[j] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gen_proj_v(const float *a, float *v, Geo q) {
+    const long long total = (long long)q.M * q.Ps;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const int m = (int)(j / q.Ps);
+        const int rem = (int)(j - (long long)m * q.Ps);
+        const int xb = rem / q.Ys, yb = rem - xb * q.Ys;
+        float s = 0.f;
+        for (int z = 0; z < q.nZ; ++z) {
+            const float *pl = a + (long long)m * q.S + (long long)z * q.P;
+            for (int dx = 0; dx < q.r; ++dx)
+                for (int dy = 0; dy < q.r; ++dy) s += pl[(long long)(xb * q.r + dx) * q.Y + yb * q.r + dy];
+        }
+        v[j] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gen_bcast(BcastArgs a) {
+    const float coef = a.coef_host * (a.coef_dev ? (float)(*a.coef_dev) : 1.f);
+    const float ca = coef * a.sa, cb = coef * a.sb;
+    double drr = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.q.N; i += stride) {
+        const long long m = i / a.q.S;
+        const int j = (int)(i - m * a.q.S);  // z*P + x*Y + y
+        const int xy = (int)(j % a.q.P);
+        const int xi = xy / a.q.Y, yi = xy - xi * a.q.Y;
+        float o = ca * a.A[j] + cb * a.B[m * a.q.Ps + (long long)(xi / a.q.r) * a.q.Ys + yi / a.q.r];
+        if (a.mask) o *= a.mask[j];
+        if (a.in) o += a.in[i];
+        a.out[i] = o;
+        drr += (double)(o * o);
+    }
+    block_store3(drr, 0.0, 0.0, a.part + (long long)blockIdx.x * DFX_NPART);
+}
+
+// ------------------------------------------------------------------------------------------
+// Small-space reductions and scalar bookkeeping
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce_u(const float *u_part, float *u, long long len, int n_chunks,
+                                                  double *part) {
+    double acc = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+        float s = 0.f;
+        for (int c = 0; c < n_chunks; ++c) s += u_part[(long long)c * len + i];
+        u[i] = s;
+        acc += (double)s * (double)s;
+    }
+    block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_v(const float *v_part, float *v, long long len, int n_zchunks) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+        float s = 0.f;
+        for (int c = 0; c < n_zchunks; ++c) s += v_part[(long long)c * len + i];
+        v[i] = s;
+    }
+}
+
+// mode 0: sum a^2 ; 1: sum mask*(a-b)^2 ; 2: sum a
+template <int KIND>
+__global__ __launch_bounds__(256) void k_reduce1(const float *a, const float *b, const float *mask,
+                                                 long long mask_n, long long n, double *part) {
+    double acc = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (KIND == 0) {
+            acc += (double)a[i] * (double)a[i];
+        } else if (KIND == 1) {
+            const double d = (double)(a[i] - b[i]);
+            const double w = mask ? (double)mask[i % mask_n] : 1.0;
+            acc += w * d * d;
+        } else {
+            acc += (double)a[i];
+        }
+    }
+    block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
+}
+
+// dst[k] = scale * sum_rows parts[row*DFX_NPART + k]; one workgroup; fixed order.
+__global__ __launch_bounds__(256) void k_fold(const double *parts, int n_rows, int nvals, double *dst,
+                                              double scale) {
+    __shared__ double sh[256];
+    for (int k = 0; k < nvals; ++k) {
+        double s = 0;
+        for (int b = threadIdx.x; b < n_rows; b += 256) s += parts[(long long)b * DFX_NPART + k];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) dst[k] = scale * sh[0];
+        __syncthreads();
+    }
+}
+
+__global__ void k_cg_start(double *s) {
+    s[DFX_S_RSOLD] = s[DFX_S_RR];
+    s[DFX_S_RSNEW] = s[DFX_S_RR];
+    s[DFX_S_ALPHA] = 0.0;
+    s[DFX_S_BETA] = 0.0;
+    s[DFX_S_TOL] = 0.0;
+    s[DFX_S_ITER] = 0.0;
+    s[DFX_S_NONFINITE] = isfinite(s[DFX_S_RR]) ? 0.0 : 1.0;
+}
+
+__global__ void k_cg_alpha(double *s, double c1, double c2, double eps) {
+    // float arithmetic where the reference has 0-dim fp32 tensors (fusion.py:444)
+    const float pap = (float)(c1 * s[DFX_S_UU] + c2 * s[DFX_S_VV]);
+    s[DFX_S_PAP] = (double)pap;
+    const float alpha = (float)s[DFX_S_RSOLD] / (pap + (float)eps);
+    s[DFX_S_ALPHA] = (double)alpha;
+}
+
+__global__ void k_cg_beta(double *s, double eps, int deferred) {
+    const double rsnew = s[DFX_S_RR];
+    s[DFX_S_RSNEW] = rsnew;
+    if (!isfinite(rsnew)) s[DFX_S_NONFINITE] += 1.0;
+    const double al = s[DFX_S_ALPHA];
+    const double pp = s[DFX_S_PP];
+    const double xx_new = deferred ? (s[DFX_S_XX] + 2.0 * al * s[DFX_S_XP] + al * al * pp) : s[DFX_S_XXNEW];
+    s[DFX_S_TOL] = fabs(al) * sqrt(pp) / sqrt(xx_new);
+    const float beta = (float)rsnew / ((float)s[DFX_S_RSOLD] + (float)eps);
+    s[DFX_S_BETA] = (double)beta;
+    s[DFX_S_RSOLD] = rsnew;
+    s[DFX_S_ITER] += 1.0;
+}
+
+__global__ void k_recip(double *dst, const double *src, double num) { dst[0] = num / src[0]; }
+
+// ------------------------------------------------------------------------------------------
+// Element-wise helpers
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_axpy(float *y, const float *x, long long n, float coef_host,
+                                              const double *coef_dev, double *part) {
+    const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f);
+    double acc = 0;
+    const long long n4 = ((((uintptr_t)y | (uintptr_t)x) & 15) == 0) ? (n >> 2) : 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = t0; i < n4; i += stride) {
+        const f4 v = ld4s(y + 4 * i) + c * ld4s(x + 4 * i);
+        st4s(y + 4 * i, v);
+        acc += (double)dot4(v, v);
+    }
+    for (long long i = 4 * n4 + t0; i < n; i += stride) {
+        const float v = y[i] + c * x[i];
+        y[i] = v;
+        acc += (double)(v * v);
+    }
+    block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
+}
+
+__global__ __launch_bounds__(256) void k_scale(float *y, long long n, const float *mask, long long mask_n,
+                                               float coef_host, const double *coef_dev) {
+    const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = y[i];
+        // fusion.py:198 assigns 0 (not multiplies): NaN/Inf under the mask must become 0 too
+        if (mask && mask[i % mask_n] == 0.f) v = 0.f;
+        y[i] = v * c;
+    }
+}
+
+struct BaseArgs {
+    const float *spc;
+    const float *zw;
+    float *x;
+    const double *coef_dev;
+    double *part;
+    float coef_host;
+    Geo q;
+    int vec;  // 4 if Y % 4 == 0 else 1
+};
+
+// bilinear source index/weight, align_corners=False, scale 1/r (ATen area_pixel_compute_source_index)
+__device__ __forceinline__ void src_idx(int i, float inv_r, int n_in, int &i0, int &i1, float &w1) {
+    float s = inv_r * ((float)i + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    w1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void k_baseline(BaseArgs a) {
+    const Geo &q = a.q;
+    const float coef = a.coef_host * (a.coef_dev ? (float)(*a.coef_dev) : 1.f);
+    const float inv_r = 1.0f / (float)q.r;
+    const int yq_n = q.Y / a.vec;
+    const long long items = (long long)q.M * q.X * yq_n;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    double acc = 0;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+        const int yq = (int)(it % yq_n);
+        const long long t2 = it / yq_n;
+        const int xi = (int)(t2 % q.X);
+        const long long m = t2 / q.X;
+        int x0, x1;
+        float wx;
+        src_idx(xi, inv_r, q.Xs, x0, x1, wx);
+        const float *s0 = a.spc + m * q.Ps + (long long)x0 * q.Ys;
+        const float *s1 = a.spc + m * q.Ps + (long long)x1 * q.Ys;
+        float up[4];
+        for (int e = 0; e < a.vec; ++e) {
+            int y0, y1;
+            float wy;
+            src_idx(yq * a.vec + e, inv_r, q.Ys, y0, y1, wy);
+            const float top = (1.f - wy) * s0[y0] + wy * s0[y1];
+            const float bot = (1.f - wy) * s1[y0] + wy * s1[y1];
+            up[e] = (1.f - wx) * top + wx * bot;
+        }
+        const long long sp = (long long)xi * q.Y + (long long)yq * a.vec;
+        float fsum = 0.f;
+        for (int z = 0; z < q.nZ; ++z) {
+            const long long zo = (long long)z * q.P + sp;
+            if (a.vec == 4) {
+                const f4 w = ld4(a.zw + zo);
+                const f4 v = {coef * (up[0] * w.x), coef * (up[1] * w.y), coef * (up[2] * w.z),
+                              coef * (up[3] * w.w)};
+                if (a.x) st4s(a.x + m * q.S + zo, v);
+                fsum += hsum(v);
+            } else {
+                const float v = coef * (up[0] * a.zw[zo]);
+                if (a.x) a.x[m * q.S + zo] = v;
+                fsum += v;
+            }
+        }
+        acc += (double)fsum;
+    }
+    block_store3(acc, 0.0, 0.0, a.part + (long long)blockIdx.x * DFX_NPART);
+}
+
+int ew_blocks(long long n, int per_thread) {
+    long long b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+    if (b < 1) b = 1;
+    if (b > DFX_EW_MAXBLOCKS) b = DFX_EW_MAXBLOCKS;
+    return (int)b;
+}
+
+int check_plan(const Geo &q, const dfx_plan *pl) {
+    if (!pl) return fail(DFX_EPLAN, "plan is NULL");
+    if (pl->steps <= 0 || pl->n_chunks <= 0 || pl->n_blocks <= 0 || pl->zc <= 0 || pl->n_zchunks <= 0)
+        return fail(DFX_EPLAN, "plan not initialised (call dfx_plan_make)");
+    if (pl->fast) {
+        if (!fast_ok(q)) return fail(DFX_EPLAN, "fast plan on a geometry that needs the generic path");
+        if (pl->zc != 4 && pl->zc != 8 && pl->zc != 16) return fail(DFX_EPLAN, "fast plan: zc must be 4, 8 or 16");
+        if ((long long)pl->zc * pl->n_zchunks < q.nZ || (long long)pl->steps * pl->n_chunks < q.M)
+            return fail(DFX_EPLAN, "plan does not cover the geometry");
+        if (pl->n_chunks > 65535 || pl->n_zchunks > 65535) return fail(DFX_EPLAN, "plan grid too large");
+        const long long nb = (long long)((q.WT + 3) / 4) * pl->n_zchunks * pl->n_chunks;
+        if (nb != pl->n_blocks) return fail(DFX_EPLAN, "plan n_blocks inconsistent");
+    } else if (pl->n_chunks != 1 || pl->n_zchunks != 1) {
+        return fail(DFX_EPLAN, "generic plan must have n_chunks = n_zchunks = 1");
+    }
+    return 0;
+}
+
+bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <int MODE>
+int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
+    dim3 grid((a.q.WT + 3) / 4, pl->n_zchunks, pl->n_chunks), block(256);
+    switch (pl->zc) {
+        case 4: hipLaunchKernelGGL((k_sweep_fast<MODE, 4>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_sweep_fast<MODE, 8>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_sweep_fast<MODE, 16>), grid, block, 0, st, a); break;
+    }
+    DFX_LAUNCH_CHECK("dfx_sweep(fast)");
+    return 0;
+}
+
+template <bool HAS_IN, bool HAS_MASK>
+int launch_bcast_fast(const BcastArgs &a, const dfx_plan *pl, hipStream_t st) {
+    dim3 grid((a.q.WT + 3) / 4, pl->n_zchunks, pl->n_chunks), block(256);
+    switch (pl->zc) {
+        case 4: hipLaunchKernelGGL((k_bcast_fast<4, HAS_IN, HAS_MASK>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_bcast_fast<8, HAS_IN, HAS_MASK>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_bcast_fast<16, HAS_IN, HAS_MASK>), grid, block, 0, st, a); break;
+    }
+    DFX_LAUNCH_CHECK("dfx_bcast(fast)");
+    return 0;
+}
+
+int fold(const double *parts, int n_rows, int nvals, double *dst, double scale, hipStream_t st) {
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, st, parts, n_rows, nvals, dst, scale);
+    DFX_LAUNCH_CHECK("fold");
+    return 0;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int dfx_version(void) { return DFX_VERSION; }
+const char *dfx_last_error(void) { return g_err; }
+
+int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (!out) return fail(DFX_EINVAL, "plan out is NULL");
+    memset(out, 0, sizeof(*out));
+    if (target_blocks <= 0) target_blocks = 2048;
+    if (fast_ok(q)) {
+        out->fast = 1;
+        int zc;
+        if (q.nZ % 16 == 0) zc = 16;
+        else if (q.nZ % 8 == 0) zc = 8;
+        else if (q.nZ % 4 == 0 || q.nZ < 8) zc = 4;
+        else zc = 8;
+        out->zc = zc;
+        out->n_zchunks = (q.nZ + zc - 1) / zc;
+        const long long groups = (long long)((q.WT + 3) / 4) * out->n_zchunks;
+        long long steps = ((long long)q.M * groups + target_blocks - 1) / target_blocks;
+        const long long lo = q.M < 16 ? q.M : 16, hi = 128;
+        if (steps < lo) steps = lo;
+        if (steps > hi) steps = hi;
+        long long n_chunks = (q.M + steps - 1) / steps;
+        if (n_chunks > 65535) {  // grid.z limit
+            n_chunks = 65535;
+            steps = (q.M + n_chunks - 1) / n_chunks;
+            n_chunks = (q.M + steps - 1) / steps;
+        }
+        out->steps = (int)steps;
+        out->n_chunks = (int)n_chunks;
+        const long long nb = groups * n_chunks;
+        if (nb > 0x7fffffffLL) return fail(DFX_EINVAL, "too many workgroups");
+        out->n_blocks = (int)nb;
+    } else {
+        out->fast = 0;
+        out->zc = 1;
+        out->n_zchunks = 1;
+        out->steps = q.M;
+        out->n_chunks = 1;
+        out->n_blocks = ew_blocks(q.N, 4);
+    }
+    out->u_part_elems = (long long)out->n_chunks * q.S;
+    out->v_part_elems = (long long)out->n_zchunks * q.M * q.Ps;
+    const long long rows = out->n_blocks > DFX_EW_MAXBLOCKS ? out->n_blocks : DFX_EW_MAXBLOCKS;
+    out->part_elems = rows * DFX_NPART;
+    return 0;
+}
+
+int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
+              double *scal, float *u_part, float *v_part, double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (int rc = check_plan(q, pl)) return rc;
+    if (mode < DFX_SWEEP_PROJECT || mode > DFX_SWEEP_PINIT) return fail(DFX_EINVAL, "dfx_sweep: bad mode");
+    if (!x || !scal || !u_part || !v_part || !part) return fail(DFX_EINVAL, "dfx_sweep: NULL buffer");
+    if (mode != DFX_SWEEP_PROJECT && (!r || !p)) return fail(DFX_EINVAL, "dfx_sweep: r and p required");
+    hipStream_t st = (hipStream_t)stream;
+    int n_rows;
+    if (pl->fast) {
+        if (!aligned16(x) || !aligned16(r) || !aligned16(p) || !aligned16(u_part))
+            return fail(DFX_EALIGN, "dfx_sweep: x, r, p, u_part must be 16-byte aligned");
+        SweepArgs a{x, r, p, scal, u_part, v_part, part, q, pl->steps};
+        int rc;
+        switch (mode) {
+            case DFX_SWEEP_PROJECT: rc = launch_sweep_fast<DFX_SWEEP_PROJECT>(a, pl, st); break;
+            case DFX_SWEEP_XP: rc = launch_sweep_fast<DFX_SWEEP_XP>(a, pl, st); break;
+            case DFX_SWEEP_P: rc = launch_sweep_fast<DFX_SWEEP_P>(a, pl, st); break;
+            default: rc = launch_sweep_fast<DFX_SWEEP_PINIT>(a, pl, st); break;
+        }
+        if (rc) return rc;
+        n_rows = pl->n_blocks;
+    } else {
+        const int nb = pl->n_blocks;
+        switch (mode) {
+            case DFX_SWEEP_PROJECT:
+                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_PROJECT>, dim3(nb), dim3(256), 0, st, x, r, p, scal, q.N, part);
+                break;
+            case DFX_SWEEP_XP:
+                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_XP>, dim3(nb), dim3(256), 0, st, x, r, p, scal, q.N, part);
+                break;
+            case DFX_SWEEP_P:
+                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_P>, dim3(nb), dim3(256), 0, st, x, r, p, scal, q.N, part);
+                break;
+            default:
+                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_PINIT>, dim3(nb), dim3(256), 0, st, x, r, p, scal, q.N, part);
+                break;
+        }
+        DFX_LAUNCH_CHECK("dfx_sweep(generic)");
+        const float *src = (mode == DFX_SWEEP_PROJECT) ? x : p;
+        hipLaunchKernelGGL(k_gen_proj_u, dim3(ew_blocks(q.S, 1)), dim3(256), 0, st, src, u_part, q);
+        DFX_LAUNCH_CHECK("dfx_sweep(generic u)");
+        hipLaunchKernelGGL(k_gen_proj_v, dim3(ew_blocks((long long)q.M * q.Ps, 1)), dim3(256), 0, st, src, v_part, q);
+        DFX_LAUNCH_CHECK("dfx_sweep(generic v)");
+        n_rows = nb;
+    }
+    // (pp, xx, xp) -> scal[PP], scal[XX], scal[XP] (consecutive slots)
+    return fold(part, n_rows, 3, scal + DFX_S_PP, 1.0, st);
+}
+
+int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in, const float *A,
+              const float *B, const float *mask, float sa, float sb, float coef_host,
+              const double *coef_dev, double *scal, double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (int rc = check_plan(q, pl)) return rc;
+    if (!out || !A || !B || !scal || !part) return fail(DFX_EINVAL, "dfx_bcast: NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    BcastArgs a{out, in, A, B, mask, coef_dev, part, sa, sb, coef_host, q, pl->steps};
+    int n_rows;
+    if (pl->fast) {
+        if (!aligned16(out) || !aligned16(in) || !aligned16(A) || !aligned16(mask))
+            return fail(DFX_EALIGN, "dfx_bcast: out, in, A, mask must be 16-byte aligned");
+        int rc;
+        if (in)
+            rc = mask ? launch_bcast_fast<true, true>(a, pl, st) : launch_bcast_fast<true, false>(a, pl, st);
+        else
+            rc = mask ? launch_bcast_fast<false, true>(a, pl, st) : launch_bcast_fast<false, false>(a, pl, st);
+        if (rc) return rc;
+        n_rows = pl->n_blocks;
+    } else {
+        n_rows = pl->n_blocks;
+        hipLaunchKernelGGL(k_gen_bcast, dim3(n_rows), dim3(256), 0, st, a);
+        DFX_LAUNCH_CHECK("dfx_bcast(generic)");
+    }
+    return fold(part, n_rows, 1, scal + DFX_S_RR, 1.0, st);
+}
+
+int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,
+                 double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (int rc = check_plan(q, pl)) return rc;
+    if (!u_part || !u || !scal || !part) return fail(DFX_EINVAL, "dfx_reduce_u: NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ew_blocks(q.S, 1);
+    hipLaunchKernelGGL(k_reduce_u, dim3(nb), dim3(256), 0, st, u_part, u, q.S, pl->n_chunks, part);
+    DFX_LAUNCH_CHECK("dfx_reduce_u");
+    return fold(part, nb, 1, scal + DFX_S_UU, 1.0, st);
+}
+
+int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, float *v, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (int rc = check_plan(q, pl)) return rc;
+    if (!v_part || !v) return fail(DFX_EINVAL, "dfx_reduce_v: NULL buffer");
+    const long long len = (long long)q.M * q.Ps;
+    hipLaunchKernelGGL(k_reduce_v, dim3(ew_blocks(len, 1)), dim3(256), 0, (hipStream_t)stream, v_part, v, len,
+                       pl->n_zchunks);
+    DFX_LAUNCH_CHECK("dfx_reduce_v");
+    return 0;
+}
+
+int dfx_sqnorm(const float *a, int64_t n, double *scal, int32_t slot, double *part, void *stream) {
+    if (!a || !scal || !part || n <= 0 || slot < 0 || slot >= DFX_NSCAL) return fail(DFX_EINVAL, "dfx_sqnorm: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ew_blocks(n, 4);
+    hipLaunchKernelGGL(k_reduce1<0>, dim3(nb), dim3(256), 0, st, a, (const float *)nullptr, (const float *)nullptr,
+                       (long long)1, (long long)n, part);
+    DFX_LAUNCH_CHECK("dfx_sqnorm");
+    return fold(part, nb, 1, scal + slot, 1.0, st);
+}
+
+int dfx_sqdiff(const float *a, const float *b, const float *mask, int64_t mask_n, int64_t n, double w,
+               double *scal, int32_t slot, double *part, void *stream) {
+    if (!a || !b || !scal || !part || n <= 0 || slot < 0 || slot >= DFX_NSCAL || (mask && mask_n <= 0))
+        return fail(DFX_EINVAL, "dfx_sqdiff: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ew_blocks(n, 4);
+    hipLaunchKernelGGL(k_reduce1<1>, dim3(nb), dim3(256), 0, st, a, b, mask, (long long)(mask ? mask_n : 1),
+                       (long long)n, part);
+    DFX_LAUNCH_CHECK("dfx_sqdiff");
+    return fold(part, nb, 1, scal + slot, w, st);
+}
+
+int dfx_sum(const float *y, int64_t n, double *scal, double *part, void *stream) {
+    if (!y || !scal || !part || n <= 0) return fail(DFX_EINVAL, "dfx_sum: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ew_blocks(n, 4);
+    hipLaunchKernelGGL(k_reduce1<2>, dim3(nb), dim3(256), 0, st, y, (const float *)nullptr, (const float *)nullptr,
+                       (long long)1, (long long)n, part);
+    DFX_LAUNCH_CHECK("dfx_sum");
+    return fold(part, nb, 1, scal + DFX_S_SUM, 1.0, st);
+}
+
+int dfx_cg_start(double *scal, void *stream) {
+    if (!scal) return fail(DFX_EINVAL, "dfx_cg_start: scal is NULL");
+    hipLaunchKernelGGL(k_cg_start, dim3(1), dim3(1), 0, (hipStream_t)stream, scal);
+    DFX_LAUNCH_CHECK("dfx_cg_start");
+    return 0;
+}
+
+int dfx_cg_alpha(double *scal, double c1, double c2, double eps, void *stream) {
+    if (!scal) return fail(DFX_EINVAL, "dfx_cg_alpha: scal is NULL");
+    hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(1), 0, (hipStream_t)stream, scal, c1, c2, eps);
+    DFX_LAUNCH_CHECK("dfx_cg_alpha");
+    return 0;
+}
+
+int dfx_cg_beta(double *scal, double eps, int32_t deferred, void *stream) {
+    if (!scal) return fail(DFX_EINVAL, "dfx_cg_beta: scal is NULL");
+    hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, (hipStream_t)stream, scal, eps, (int)deferred);
+    DFX_LAUNCH_CHECK("dfx_cg_beta");
+    return 0;
+}
+
+int dfx_axpy(float *y, const float *x, int64_t n, float coef_host, const double *coef_dev, double *scal,
+             double *part, void *stream) {
+    if (!y || !x || !scal || !part || n <= 0) return fail(DFX_EINVAL, "dfx_axpy: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ew_blocks(n, 16);
+    hipLaunchKernelGGL(k_axpy, dim3(nb), dim3(256), 0, st, y, x, (long long)n, coef_host, coef_dev, part);
+    DFX_LAUNCH_CHECK("dfx_axpy");
+    return fold(part, nb, 1, scal + DFX_S_XXNEW, 1.0, st);
+}
+
+int dfx_scale(float *y, int64_t n, const float *mask, int64_t mask_n, float coef_host,
+              const double *coef_dev, void *stream) {
+    if (!y || n <= 0 || (mask && mask_n <= 0)) return fail(DFX_EINVAL, "dfx_scale: bad argument");
+    hipLaunchKernelGGL(k_scale, dim3(ew_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, y, (long long)n, mask,
+                       (long long)(mask ? mask_n : 1), coef_host, coef_dev);
+    DFX_LAUNCH_CHECK("dfx_scale");
+    return 0;
+}
+
+int dfx_recip(double *dst, const double *src, double num, void *stream) {
+    if (!dst || !src) return fail(DFX_EINVAL, "dfx_recip: NULL");
+    hipLaunchKernelGGL(k_recip, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, src, num);
+    DFX_LAUNCH_CHECK("dfx_recip");
+    return 0;
+}
+
+int dfx_baseline_init(const dfx_geom *g, const float *spc, const float *zw, float *x, float coef_host,
+                      const double *coef_dev, double *scal, double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (!spc || !zw || !scal || !part) return fail(DFX_EINVAL, "dfx_baseline_init: NULL buffer");
+    const int vec = (q.Y % 4 == 0 && aligned16(zw) && aligned16(x)) ? 4 : 1;
+    BaseArgs a{spc, zw, x, coef_dev, part, coef_host, q, vec};
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ew_blocks((long long)q.M * q.X * (q.Y / vec), 1);
+    hipLaunchKernelGGL(k_baseline, dim3(nb), dim3(256), 0, st, a);
+    DFX_LAUNCH_CHECK("dfx_baseline_init");
+    return fold(part, nb, 1, scal + DFX_S_SUM, 1.0, st);
+}
+
+}  // extern "C"

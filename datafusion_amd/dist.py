@@ -1,0 +1,35 @@
+"""z-sharding helpers: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The volume is split along z.  The ST term (u) is local to a shard; the only
+exchanges per CG iteration are the sum of the spc-sized RD partial v and a handful of scalars.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def z_partition(n_z: int, world: int, rank: int) -> tuple[int, int]:
+    """Planes [z0, z1) owned by `rank`: contiguous, sizes differ by at most one."""
+    if world > n_z:
+        raise ValueError(f"cannot shard {n_z} z-planes over {world} ranks")
+    base, rem = divmod(n_z, world)
+    z0 = rank * base + min(rank, rem)
+    return z0, z0 + base + (1 if rank < rem else 0)
+
+
+class ShardComm:
+    """Sum-all-reduce over the shard group; the identity when there is one shard."""
+
+    def __init__(self, group=None):
+        if group is None or not dist.is_initialized():
+            self.group, self.size, self.rank = None, 1, 0
+        else:
+            self.group = group if group is not True else dist.group.WORLD
+            self.size = dist.get_world_size(self.group)
+            self.rank = dist.get_rank(self.group)
+
+    def sum_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t

@@ -1,0 +1,357 @@
+"""Host side of the MI355X FusionCG / FusionAdam path: the reference's Python surface
+(datafusion/fusion.py:101-496: same class names, keyword arguments, defaults, return values and
+exceptions) over the HIP kernels in libdfx.so.  torch is used for device memory, streams,
+torch.distributed (RCCL) and a few operations on the *small* cmos/spc-sized arrays; every pass
+over a 5-D vector is a hand-written kernel (see kernels.py / csrc/dfx_kernels.hip).
+
+Differences from the reference a caller can observe (documented, deliberate):
+  * device defaults to "cuda" and must be an AMD GPU - there is no CPU path;
+  * self.x is updated in place (the reference rebinds a fresh tensor each iteration,
+    fusion.py:445) and self.prev_x stays None: ||x - prev_x|| is |alpha| ||p|| exactly, so the
+    clone of fusion.py:441 and the subtraction of fusion.py:250 are never materialised;
+  * with tol=None the finiteness assertion of fusion.py:448 is raised after the loop (the
+    device keeps a sticky flag) instead of at the offending iteration: no host sync per iteration;
+  * loss() is not evaluated every CG iteration unless verbose=True (fusion.py:458 computes it
+    only to feed the progress bar; it does not influence x);
+  * `group=` (a torch.distributed process group) z-shards the volume: every rank passes the full
+    (small) spc and cmos, owns planes z_range of x, and gets its own shard back.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _cabi as cabi
+from .dist import ShardComm, z_partition
+from .kernels import HipKernels
+
+
+def squared_l2(x):
+    """fusion.py:12-18."""
+    return (x ** 2).sum()
+
+
+class SumOperator:
+    """API mirror of fusion.py:21-51 (T, S, D as stand-alone callables on torch tensors).
+    The solvers never call these: the sums are fused into dfx_sweep and the normalised
+    transposes are broadcast-on-read inside dfx_bcast."""
+
+    def __init__(self, size: int = 1, integral_dim: int = 0):
+        self.size = size
+        self.integral_dim = integral_dim
+
+    def T(self, y: torch.Tensor) -> torch.Tensor:
+        shape = list(y.shape)
+        shape[self.integral_dim] *= self.size
+        return (y / self.size).unsqueeze(self.integral_dim + 1).expand(
+            *y.shape[: self.integral_dim + 1], self.size, *y.shape[self.integral_dim + 1:]).reshape(shape)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        self.size = x.shape[self.integral_dim]  # fusion.py:50
+        return x.sum(dim=self.integral_dim, keepdim=True)
+
+
+class SumPoolOperator:
+    """API mirror of fusion.py:54-98 (R and its normalised transpose) on (nT, nL, 1, X, Y) tensors."""
+
+    def __init__(self, size: int = 4, channels: int = 16, device: str = "cuda"):
+        self.size = size
+        self.channels = channels
+
+    def T(self, y: torch.Tensor) -> torch.Tensor:
+        r = self.size
+        return (y / r ** 2).repeat_interleave(r, dim=-2).repeat_interleave(r, dim=-1)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        r = self.size
+        s = x.shape
+        return x.reshape(*s[:-2], s[-2] // r, r, s[-1] // r, r).sum(dim=(-3, -1))
+
+
+class Fusion:
+    """Base class (fusion.py:101-292): input conversion, masks, energy normalisation, init."""
+
+    _backend_cls = HipKernels  # tests swap in a CPU stand-in to exercise the sharding logic under gloo
+
+    def __init__(self, spc, cmos, *, weights: dict, init_type: str, tol: float | None = 3e-3,
+                 mask_noise: bool = False, total_energy: float = 1.0, device: str = "cuda", seed: int = 42,
+                 verbose: bool = False, group=None, defer_x: bool = True, target_blocks: int = 0):
+        dev = torch.device(device)
+        self.spc = self._to_device(spc, "spc", dev)      # fusion.py:135-148
+        self.cmos = self._to_device(cmos, "cmos", dev)
+        self.verbose = verbose
+        self.weights = weights
+        self.init_type = init_type
+        self.curr_iter = 0
+        self.tol = tol
+        self.seed = seed
+        self.mask_noise = mask_noise
+        self.device = device
+        self.total_energy = float(total_energy)
+        self.n_times, self.n_lambdas = int(self.spc.shape[0]), int(self.spc.shape[1])
+        self.z_dim, self.xy_dim = int(self.cmos.shape[0]), int(self.cmos.shape[1])
+        self.x_shape = (self.n_times, self.n_lambdas, self.z_dim, int(self.cmos.shape[1]), int(self.cmos.shape[2]))
+        self.spatial_increase = int(self.cmos.shape[-1]) // int(self.spc.shape[-1])   # fusion.py:169
+        self.prev_x = None
+        r = self.spatial_increase
+        if r < 1 or self.cmos.shape[1] != r * self.spc.shape[2] or self.cmos.shape[2] != r * self.spc.shape[3]:
+            raise ValueError("cmos (z, x, y) must be an integer multiple r of spc (t, l, x/r, y/r) in x and y")
+        self.defer_x = bool(defer_x) and not verbose
+
+        self.T = SumOperator(size=self.n_times, integral_dim=0)        # fusion.py:172-179
+        self.S = SumOperator(size=self.n_lambdas, integral_dim=1)
+        self.D = SumOperator(size=self.z_dim, integral_dim=2)
+        self.R = SumPoolOperator(size=r, channels=self.n_lambdas, device=device)
+
+        # z-sharding (new): this rank owns planes [z0, z1)
+        self.comm = ShardComm(group)
+        self.z_range = z_partition(self.z_dim, self.comm.size, self.comm.rank)
+        z0, z1 = self.z_range
+        self.local_shape = (self.n_times, self.n_lambdas, z1 - z0, self.x_shape[3], self.x_shape[4])
+
+        self.spc_mask, self.cmos_mask = self._get_masks()               # fusion.py:182
+        if self.mask_noise:                                              # fusion.py:185-187
+            self.spc = self.spc * self.spc_mask.float()
+            self.cmos = self.cmos * self.cmos_mask.float()
+        self.spc_mask = self.spc_mask.squeeze(0)                         # fusion.py:189
+        self.spc = self.normalize_energy(self.spc, total_energy).contiguous()     # fusion.py:192-193
+        self.cmos = self.normalize_energy(self.cmos, total_energy).contiguous()
+
+        self.k = self._backend_cls(self.n_times, self.n_lambdas, z1 - z0, self.x_shape[3], self.x_shape[4], r, dev,
+                                   target_blocks)
+        self._cmos_loc = self.cmos[z0:z1].contiguous()
+        self._cmask_loc = self.cmos_mask[z0:z1].float().contiguous()
+        self._smask_f = self.spc_mask.float().contiguous()
+        self.x = self._initialize()                                     # fusion.py:196-199
+
+    # ---- helpers ------------------------------------------------------------------------
+    @staticmethod
+    def _to_device(a, name, dev):
+        if isinstance(a, np.ndarray):
+            return torch.from_numpy(a.astype(np.float32)).to(dev)
+        if isinstance(a, torch.Tensor):
+            return a.to(dev).float()
+        raise TypeError(f"{name} must be a numpy.ndarray or torch.Tensor")
+
+    @staticmethod
+    def normalize_energy(tensor: torch.Tensor, total_energy: int | float = 1) -> torch.Tensor:
+        """fusion.py:204-209 - for the small (spc / cmos sized) tensors; the 5-D x is normalised by
+        dfx_sum + dfx_scale (or inside dfx_baseline_init)."""
+        return total_energy * tensor / tensor.sum()
+
+    def _get_masks(self):
+        """fusion.py:280-292 on the small arrays."""
+        cmos_mask = self.cmos > (0.05 * self.cmos.max())
+        any_z = cmos_mask.any(dim=0).unsqueeze(0).float()
+        size = [int(self.spc.shape[-2]), int(self.spc.shape[-1])]
+        if list(any_z.shape[-2:]) != size:
+            any_z = F.interpolate(any_z.unsqueeze(0), size=size, mode="bilinear", align_corners=False,
+                                  antialias=False).squeeze(0)
+        return any_z.bool(), cmos_mask
+
+    def _initialize(self) -> torch.Tensor:
+        """fusion.py:254-272 + the masking / normalisation of fusion.py:197-199, on the device."""
+        k, z0, z1 = self.k, *self.z_range
+        if self.init_type == "baseline":
+            # baseline.py:46 cmos / sum_z cmos needs every plane: computed on the full (small) cmos
+            zw = self.cmos / self.cmos.sum(dim=0, keepdim=True)
+            if self.mask_noise:
+                zw = torch.where(self.cmos_mask, zw, torch.zeros_like(zw))   # fusion.py:198
+            zw = zw[z0:z1].contiguous()
+            x = k.new_vector()
+            k.baseline_init(self.spc, zw, None, 1.0, None)       # pass 1: SUM only, nothing written
+            self.comm.sum_(k.scal[cabi.S_SUM:cabi.S_SUM + 1])
+            k.recip(cabi.S_SCALE, cabi.S_SUM, self.total_energy)
+            k.baseline_init(self.spc, zw, x, 1.0, cabi.S_SCALE)  # pass 2: x = E/sum * up(spc) * zw
+            return x
+        if self.init_type == "random":
+            # the reference draws on `device`'s generator (fusion.py:262-264); parity is defined against
+            # its torch-CPU run, so draw on the CPU generator and upload this rank's planes
+            torch.manual_seed(self.seed)
+            lo, hi = self.cmos.min().cpu(), self.cmos.max().cpu()
+            full = (lo - hi) * torch.rand(self.x_shape) + hi
+            x = full[:, :, z0:z1].contiguous().to(k.device)
+        elif self.init_type == "zeros":
+            torch.manual_seed(self.seed)
+            x = torch.zeros(self.local_shape, dtype=torch.float32, device=k.device)
+        else:
+            raise ValueError("Invalid initialization type.")                 # fusion.py:271
+        if self.mask_noise:
+            k.scale(x, self._cmask_loc, 1.0, None)                           # fusion.py:198
+        k.sum(x)
+        self.comm.sum_(k.scal[cabi.S_SUM:cabi.S_SUM + 1])
+        k.recip(cabi.S_SCALE, cabi.S_SUM, self.total_energy)
+        k.scale(x, None, 1.0, cabi.S_SCALE)                                  # fusion.py:199
+        return x
+
+    def _project(self, x) -> None:
+        """u(x) -> k.u (local planes), v(x) -> k.v (summed over shards)."""
+        self.k.sweep(cabi.SWEEP_PROJECT, x)
+        self.comm.sum_(self.k.v)
+
+    def _losses_from_uv(self):
+        k = self.k
+        w1, w2 = float(self.weights["spatial"]), float(self.weights["spectro_temporal"])
+        k.sqdiff(self._cmos_loc, k.u, self._cmask_loc if self.mask_noise else None, w1, cabi.S_LOSS1)
+        k.sqdiff(self.spc, k.v, self._smask_f if self.mask_noise else None, w2, cabi.S_LOSS2)
+        self.comm.sum_(k.scal[cabi.S_LOSS1:cabi.S_LOSS1 + 1])
+        return k.scal[cabi.S_LOSS1].float(), k.scal[cabi.S_LOSS2].float()
+
+    def loss(self):
+        """fusion.py:211-242 -> (spatial_loss, spectro_temporal_loss) as 0-dim device tensors."""
+        x = self.x.detach() if isinstance(self.x, torch.Tensor) else self.x
+        self._project(x)
+        return self._losses_from_uv()
+
+    def tolerance(self) -> torch.Tensor:
+        """fusion.py:244-252: ||x - prev_x|| / ||x|| of the last completed iteration (device scalar)."""
+        return self.k.scal[cabi.S_TOL].float()
+
+    def _result(self, return_numpy: bool):
+        x = self.x.detach() if isinstance(self.x, torch.Tensor) else self.x
+        if return_numpy:                                                     # fusion.py:489-496
+            return x.cpu().numpy(), self.spc.cpu().numpy(), self.cmos.cpu().numpy()
+        return self.x, self.spc, self.cmos
+
+    def __call__(self, *args, **kwargs):
+        raise NotImplementedError("This method should be implemented by subclasses.")
+
+
+class FusionCG(Fusion):
+    """Conjugate gradient on the normal equations (fusion.py:389-496)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.w1 = self.weights["spatial"]
+        self.w2 = self.weights["spectro_temporal"]
+        self._r = self._p = None
+
+    def _finish_projection(self) -> None:
+        """After a sweep that produced u(p), v(p) partials: cross-shard sums + ||v||^2."""
+        k, c = self.k, self.comm
+        c.sum_(k.v)                                   # RD partials: the one real exchange
+        k.sqnorm_v()                                  # VV identical on every rank
+        c.sum_(k.scal[cabi.S_UU:cabi.S_XP + 1])       # UU, PP, XX, XP partials
+
+    @torch.no_grad()
+    def __call__(self, max_iterations: int, eps: float = 1e-10, return_numpy: bool = True):
+        k, c = self.k, self.comm
+        n_t, n_l, n_z, r = self.n_times, self.n_lambdas, self.z_dim, self.spatial_increase
+        # A p = c1 * bcast_{t,l} u(p) + c2 * bcast_{z,block} v(p)   (fusion.py:423-426 with the 1/size
+        # factors of the normalised transposes folded in)
+        c1, c2 = float(self.w1) / (n_t * n_l), float(self.w2) / (n_z * r * r)
+        if self._r is None:
+            self._r, self._p = k.new_vector(), k.new_vector()
+        x, rv, pv = self.x, self._r, self._p
+        deferred = self.defer_x
+        history = np.zeros((int(max_iterations), len(self.weights) + 2)) if self.verbose else None
+
+        # r0 = b - A(x0) = c1 bcast(cmos_n - u(x0)) + c2 bcast(spc_n - v(x0))      (fusion.py:428-435)
+        self._project(x)
+        du = self._cmos_loc - k.u
+        dv = self.spc - k.v
+        k.bcast(rv, None, du, dv, None, c1, c2, 1.0, None)
+        c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
+        k.cg_start()                                                            # rsold (fusion.py:437)
+        k.sweep(cabi.SWEEP_PINIT, x, rv, pv)                                    # p = r (fusion.py:436)
+        self._finish_projection()
+
+        pending_x = False
+        for i in range(int(max_iterations)):
+            self.curr_iter += 1
+            k.cg_alpha(c1, c2, eps)                                             # fusion.py:443-444
+            if not deferred:
+                k.axpy(x, pv, 1.0, cabi.S_ALPHA)                                # fusion.py:445
+                c.sum_(k.scal[cabi.S_XXNEW:cabi.S_XXNEW + 1])
+            else:
+                pending_x = True
+            k.bcast(rv, rv, k.u, k.v, None, c1, c2, -1.0, cabi.S_ALPHA)         # fusion.py:446-447
+            c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
+            k.cg_beta(eps, deferred)                                            # rsnew, tol, beta
+            if self.tol is not None or self.verbose:
+                s = k.scal.cpu()                                                # one sync, as fusion.py:448
+                assert bool(s[cabi.S_NONFINITE] == 0), "Conjugate gradient diverged"
+                tolerance = float(s[cabi.S_TOL]) if self.tol is not None else None
+                if self.tol is not None and tolerance < self.tol:              # fusion.py:451-453
+                    break
+            if self.verbose:                                                    # fusion.py:458-478
+                l1, l2 = self.loss()                                            # x is current: defer_x is off
+                history[i] = [float(l1), float(l2), float(l1) + float(l2), float(s[cabi.S_RSNEW])]
+            k.sweep(cabi.SWEEP_XP if deferred else cabi.SWEEP_P, x, rv, pv)     # fusion.py:445,455
+            pending_x = False
+            self._finish_projection()
+        if pending_x:                                   # left the loop by tolerance: x_{i+1} still owed
+            k.axpy(x, pv, 1.0, cabi.S_ALPHA)
+        s = k.scal.cpu()
+        assert bool(s[cabi.S_NONFINITE] == 0), "Conjugate gradient diverged"   # fusion.py:448
+        self.history = history
+        return self._result(return_numpy)
+
+
+class _FusionLossFn(torch.autograd.Function):
+    """loss() of fusion.py:211-242 as one autograd node over the HIP kernels: forward = dfx_sweep
+    (PROJECT) + small-space residuals; backward = dfx_bcast writing
+    g1 * (-2 w1) bcast_{t,l}(m1 (cmos - u)) + g2 * (-2 w2) bcast_{z,block}(m2 (spc - v))."""
+
+    @staticmethod
+    def forward(ctx, x, fusion, mask_grad):
+        fusion._project(x.detach())
+        k = fusion.k
+        du = fusion._cmos_loc - k.u
+        dv = fusion.spc - k.v
+        if fusion.mask_noise:
+            du = du * fusion._cmask_loc
+            dv = dv * fusion._smask_f
+        ctx.fusion, ctx.mask_grad = fusion, mask_grad
+        ctx.save_for_backward(du, dv)
+        l1, l2 = fusion._losses_from_uv()
+        return l1.clone(), l2.clone()
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        f = ctx.fusion
+        du, dv = ctx.saved_tensors
+        w1, w2 = float(f.weights["spatial"]), float(f.weights["spectro_temporal"])
+        A = ((-2.0 * w1) * g1.float()) * du
+        B = ((-2.0 * w2) * g2.float()) * dv
+        grad = f.k.new_vector()
+        f.k.bcast(grad, None, A.contiguous(), B.contiguous(), f._cmask_loc if ctx.mask_grad else None,
+                  1.0, 1.0, 1.0, None)
+        return grad, None, None
+
+
+class FusionAdam(Fusion):
+    """Adam + backprop variant (fusion.py:295-386)."""
+
+    def loss_autograd(self, mask_grad: bool = False):
+        return _FusionLossFn.apply(self.x, self, mask_grad)
+
+    def __call__(self, lr: float, max_iterations: int, non_neg: bool = False, return_numpy: bool = True):
+        history = np.zeros((max_iterations, len(self.weights) + 1)) if self.verbose else None
+        self.x = torch.nn.Parameter(self.x, requires_grad=True)                 # fusion.py:324-325
+        optimizer = torch.optim.Adam([self.x], lr=lr, amsgrad=False)
+        for i in range(max_iterations):
+            self.curr_iter += 1
+            prev_x = self.x.detach().clone() if self.tol is not None else None
+            optimizer.zero_grad()
+            # the gradient mask of fusion.py:274-278 is applied inside the backward kernel
+            spatial_loss, spectro_temporal_loss = self.loss_autograd(mask_grad=self.mask_noise)
+            loss = spatial_loss + spectro_temporal_loss
+            loss.backward()
+            optimizer.step()
+            if non_neg:                                                         # fusion.py:344-346
+                with torch.no_grad():
+                    self.x.clamp_(min=0)
+            tolerance = None
+            if self.tol is not None:                                            # fusion.py:348
+                with torch.no_grad():
+                    d = torch.stack([((self.x - prev_x) ** 2).sum(), (self.x.detach() ** 2).sum()]).double()
+                    self.comm.sum_(d)
+                    tolerance = float(torch.sqrt(d[0] / d[1]))
+            if tolerance is not None and tolerance < self.tol:
+                break
+            if self.verbose:
+                history[i] = [float(spatial_loss), float(spectro_temporal_loss), float(loss)]
+        self.history = history
+        return self._result(return_numpy)

@@ -1,0 +1,142 @@
+"""HipKernels: the (only) compute backend - one z-shard's buffers + launches into libdfx.so.
+
+Every method enqueues kernels on torch's current HIP stream of `device` and returns without
+synchronising.  The CG scalars live in `self.scal` (double[NSCAL]) on the device.
+The orchestration in solver.py is written against this small interface so that its sharding /
+collective logic can be exercised on CPU (gloo) with a stand-in backend supplied by the tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _cabi as cabi
+
+
+class HipKernels:
+    def __init__(self, n_t: int, n_l: int, n_z_local: int, X: int, Y: int, r: int, device, target_blocks: int = 0):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise cabi.DfxError(f"datafusion_amd runs on AMD GPUs only (got device={device!r}); there is no CPU path")
+        self.lib = cabi.lib()
+        self.shape = (n_t, n_l, n_z_local, X, Y)
+        self.r = r
+        self.M, self.S = n_t * n_l, n_z_local * X * Y
+        self.N = self.M * self.S
+        self.Xs, self.Ys = X // r, Y // r
+        self.geom = cabi.Geom(n_t, n_l, n_z_local, X, Y, r, 0)
+        self.plan = cabi.Plan()
+        cabi.check(self.lib.dfx_plan_make(C.byref(self.geom), target_blocks, C.byref(self.plan)), "dfx_plan_make")
+        dev = self.device
+        self.scal = torch.zeros(cabi.NSCAL, dtype=torch.float64, device=dev)
+        self.part = torch.empty(self.plan.part_elems, dtype=torch.float64, device=dev)
+        self.u_part = torch.empty(self.plan.u_part_elems, dtype=torch.float32, device=dev)
+        self.v_part = torch.empty(self.plan.v_part_elems, dtype=torch.float32, device=dev)
+        self.u = torch.empty((n_z_local, X, Y), dtype=torch.float32, device=dev)
+        # with one z-chunk the sweep writes v directly: no reduce pass, v aliases v_part
+        self._v_own = (torch.empty((n_t, n_l, self.Xs, self.Ys), dtype=torch.float32, device=dev)
+                       if self.plan.n_zchunks > 1 else None)
+        self.v = self._v_own if self._v_own is not None else self.v_part.view(n_t, n_l, self.Xs, self.Ys)
+
+    # -- helpers --------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _g(self):
+        return C.byref(self.geom), C.byref(self.plan)
+
+    def slot_ptr(self, slot: int) -> int:
+        return self.scal.data_ptr() + 8 * slot
+
+    def new_vector(self) -> torch.Tensor:
+        return torch.empty(self.shape, dtype=torch.float32, device=self.device)
+
+    def _chk(self, *ts):
+        for t in ts:
+            if t is not None:
+                assert t.device == self.scal.device and t.dtype == torch.float32 and t.is_contiguous()
+
+    # -- 5-D passes -----------------------------------------------------------------------
+    def sweep(self, mode: int, x, r=None, p=None) -> None:
+        """u(.) -> self.u (+UU), local v partial -> self.v, PP/XX/XP -> scal."""
+        self._chk(x, r, p)
+        for t in (x, r, p):
+            assert t is None or t.numel() == self.N
+        g, pl = self._g()
+        s = self._stream()
+        cabi.check(self.lib.dfx_sweep(mode, g, pl, cabi.ptr(x), cabi.ptr(r), cabi.ptr(p), cabi.ptr(self.scal),
+                                      cabi.ptr(self.u_part), cabi.ptr(self.v_part), cabi.ptr(self.part), s),
+                   "dfx_sweep")
+        cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
+                                         cabi.ptr(self.part), s), "dfx_reduce_u")
+        if self._v_own is not None:
+            cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), s), "dfx_reduce_v")
+
+    def sqnorm_v(self) -> None:
+        """VV = ||v||^2 (call after the cross-shard sum of v)."""
+        cabi.check(self.lib.dfx_sqnorm(cabi.ptr(self.v), self.v.numel(), cabi.ptr(self.scal), cabi.S_VV,
+                                       cabi.ptr(self.part), self._stream()), "dfx_sqnorm")
+
+    def bcast(self, out, inp, A, B, mask, sa: float, sb: float, coef_host: float, coef_slot: int | None) -> None:
+        """out = inp + coef*mask*(sa*A[z,x,y] + sb*B[t,l,x/r,y/r]); RR = sum(out^2)."""
+        self._chk(out, inp, A, B, mask)
+        assert out.numel() == self.N and A.numel() == self.S and B.numel() == self.M * self.Xs * self.Ys
+        assert inp is None or inp.numel() == self.N
+        assert mask is None or mask.numel() == self.S
+        g, pl = self._g()
+        cabi.check(self.lib.dfx_bcast(g, pl, cabi.ptr(out), cabi.ptr(inp), cabi.ptr(A), cabi.ptr(B), cabi.ptr(mask),
+                                      sa, sb, coef_host, None if coef_slot is None else self.slot_ptr(coef_slot),
+                                      cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_bcast")
+
+    def axpy(self, y, x, coef_host: float, coef_slot: int | None) -> None:
+        """y += coef * x ; XXNEW = ||y||^2."""
+        self._chk(y, x)
+        assert y.numel() == x.numel()
+        cabi.check(self.lib.dfx_axpy(cabi.ptr(y), cabi.ptr(x), y.numel(), coef_host,
+                                     None if coef_slot is None else self.slot_ptr(coef_slot), cabi.ptr(self.scal),
+                                     cabi.ptr(self.part), self._stream()), "dfx_axpy")
+
+    def scale(self, y, mask, coef_host: float, coef_slot: int | None) -> None:
+        self._chk(y, mask)
+        cabi.check(self.lib.dfx_scale(cabi.ptr(y), y.numel(), cabi.ptr(mask), 0 if mask is None else mask.numel(),
+                                      coef_host, None if coef_slot is None else self.slot_ptr(coef_slot),
+                                      self._stream()), "dfx_scale")
+
+    def sum(self, y) -> None:
+        """SUM = sum(y)."""
+        self._chk(y)
+        cabi.check(self.lib.dfx_sum(cabi.ptr(y), y.numel(), cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()),
+                   "dfx_sum")
+
+    def recip(self, dst_slot: int, src_slot: int, num: float) -> None:
+        cabi.check(self.lib.dfx_recip(self.slot_ptr(dst_slot), self.slot_ptr(src_slot), num, self._stream()),
+                   "dfx_recip")
+
+    def sqdiff(self, a, b, mask, w: float, slot: int) -> None:
+        """scal[slot] = w * sum mask*(a-b)^2 (mask periodic over the flat index)."""
+        self._chk(a, b, mask)
+        assert a.numel() == b.numel()
+        cabi.check(self.lib.dfx_sqdiff(cabi.ptr(a), cabi.ptr(b), cabi.ptr(mask), 0 if mask is None else mask.numel(),
+                                       a.numel(), w, cabi.ptr(self.scal), slot, cabi.ptr(self.part), self._stream()),
+                   "dfx_sqdiff")
+
+    def baseline_init(self, spc, zw, x, coef_host: float, coef_slot: int | None) -> None:
+        """x = coef * up(spc) * zw (x may be None: SUM only)."""
+        self._chk(spc, zw, x)
+        assert spc.numel() == self.M * self.Xs * self.Ys and zw.numel() == self.S
+        g, _ = self._g()
+        cabi.check(self.lib.dfx_baseline_init(g, cabi.ptr(spc), cabi.ptr(zw), cabi.ptr(x), coef_host,
+                                              None if coef_slot is None else self.slot_ptr(coef_slot),
+                                              cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()),
+                   "dfx_baseline_init")
+
+    # -- scalar bookkeeping ---------------------------------------------------------------
+    def cg_start(self) -> None:
+        cabi.check(self.lib.dfx_cg_start(cabi.ptr(self.scal), self._stream()), "dfx_cg_start")
+
+    def cg_alpha(self, c1: float, c2: float, eps: float) -> None:
+        cabi.check(self.lib.dfx_cg_alpha(cabi.ptr(self.scal), c1, c2, eps, self._stream()), "dfx_cg_alpha")
+
+    def cg_beta(self, eps: float, deferred: bool) -> None:
+        cabi.check(self.lib.dfx_cg_beta(cabi.ptr(self.scal), eps, int(deferred), self._stream()), "dfx_cg_beta")

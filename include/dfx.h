@@ -1,0 +1,151 @@
+/* dfx.h - C ABI of libdfx.so: hand-written gfx950 (MI355X) kernels for the FusionCG /
+ * FusionAdam / baseline() hot path of FluoLab/datafusion.
+ *
+ * The reference has no FFI for this path (it is eager torch); each entry point
+ * below names the reference lines (paths relative to the reference checkout) whose work it
+ * replaces.  All tensors are fp32, layout (t, lambda, z, x, y) with y contiguous, exactly as
+ * datafusion/fusion.py:162-168.  With z-sharding, nZ in dfx_geom is the LOCAL plane count.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DFX_E* code for a rejected argument,
+ *     or a positive hipError_t; dfx_last_error() gives the message (thread local).
+ *   - no entry point allocates, frees or synchronises; the caller owns every buffer
+ *     (sizes come from dfx_plan_make) and passes the hipStream_t to launch on.
+ *   - pointers are device pointers; big vectors must be 16-byte aligned.
+ *   - reductions are deterministic: per-workgroup double partials in the caller's `part`
+ *     workspace, folded in a fixed order by a one-workgroup kernel launched by the same entry
+ *     point into a slot of the device-resident state `scal`; no float atomics anywhere.
+ *   - `scal` (double[DFX_NSCAL]) lives on the device for the whole solve: alpha, beta and the
+ *     norms never visit the host unless the caller copies them.
+ */
+#ifndef DFX_H
+#define DFX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFX_VERSION 100
+
+enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
+
+/* Extents of the (local shard of the) 5-D volume; X = r*Xs, Y = r*Ys (fusion.py:158-169). */
+typedef struct dfx_geom {
+    int64_t nT, nL, nZ, X, Y;
+    int32_t r;        /* spatial_increase, fusion.py:169 */
+    int32_t pad_;
+} dfx_geom;
+
+/* Launch plan + workspace sizes for one geometry.  fast=1: float4 wave-tile kernels
+ * (r == 4, Y % 64 == 0); fast=0: shape-generic kernels. */
+typedef struct dfx_plan {
+    int32_t fast;
+    int32_t zc;          /* z planes a workgroup keeps in registers */
+    int32_t n_zchunks;   /* ceil(nZ / zc) */
+    int32_t steps;       /* (t,lambda) slabs per workgroup */
+    int32_t n_chunks;    /* ceil(nT*nL / steps) */
+    int32_t n_blocks;    /* workgroups per sweep / bcast launch */
+    int64_t u_part_elems;    /* floats: n_chunks * nZ*X*Y */
+    int64_t v_part_elems;    /* floats: n_zchunks * nT*nL*Xs*Ys */
+    int64_t part_elems;      /* doubles: max(n_blocks, DFX_EW_MAXBLOCKS) * DFX_NPART */
+} dfx_plan;
+
+/* Slots of the device-resident state `scal` (double[DFX_NSCAL]). */
+enum {
+    DFX_S_RSOLD = 0, DFX_S_RSNEW = 1, DFX_S_PAP = 2, DFX_S_ALPHA = 3, DFX_S_BETA = 4,
+    DFX_S_TOL = 5,
+    DFX_S_UU = 6,   /* ||u(p)||^2 over the local z planes (dfx_reduce_u)            */
+    DFX_S_PP = 7,   /* ||p||^2 (dfx_sweep)                                            */
+    DFX_S_XX = 8,   /* ||x||^2 at the time p was formed (dfx_sweep)                   */
+    DFX_S_XP = 9,   /* <x, p> (dfx_sweep)                                             */
+    DFX_S_VV = 10,  /* ||v(p)||^2 after the cross-shard sum (dfx_sqnorm)              */
+    DFX_S_RR = 11,  /* ||out||^2 of the last dfx_bcast                                */
+    DFX_S_XXNEW = 12, /* ||y||^2 of the last dfx_axpy                                 */
+    DFX_S_NONFINITE = 13, /* sticky: >0 once rsnew was not finite (fusion.py:448)     */
+    DFX_S_ITER = 14,
+    DFX_S_SUM = 15, /* plain sum (dfx_sum, dfx_baseline_init)                         */
+    DFX_S_SCALE = 16, /* dfx_recip output by convention                               */
+    DFX_S_LOSS1 = 17, DFX_S_LOSS2 = 18, /* dfx_sqdiff outputs by convention           */
+    DFX_NSCAL = 32
+};
+#define DFX_NPART 4          /* doubles per workgroup row of `part` */
+#define DFX_EW_MAXBLOCKS 2048 /* grid cap of the element-wise kernels */
+
+/* sweep modes */
+enum {
+    DFX_SWEEP_PROJECT = 0, /* read x: u(x), v(x), XX = ||x||^2                                  */
+    DFX_SWEEP_XP = 1,      /* x += alpha p ; p = r + beta p ; u(p), v(p), PP, XX, XP             */
+    DFX_SWEEP_P = 2,       /* p = r + beta p ; u(p), v(p), PP          (x untouched)             */
+    DFX_SWEEP_PINIT = 3    /* p = r ; u(p), v(p), PP, XX, XP    (reads x, r; writes p)           */
+};
+
+int dfx_version(void);
+const char *dfx_last_error(void);
+
+/* Choose the launch plan and workspace sizes.  target_blocks <= 0 -> default. */
+int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out);
+
+/* One pass over the 5-D vectors (replaces, fused: T,S,D,R forward of fusion.py:44-51,89-98 as
+ * called from the closure A fusion.py:423-426; the axpy `x + p*alpha` fusion.py:445; the
+ * direction update fusion.py:455; the dot products / norms of fusion.py:250-251,444).
+ * alpha, beta are read from scal[DFX_S_ALPHA], scal[DFX_S_BETA] on the device.
+ * Outputs: u_part [n_chunks][nZ][X][Y], v_part [n_zchunks][nT*nL][Xs][Ys], scal[PP, XX, XP]. */
+int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
+              double *scal, float *u_part, float *v_part, double *part, void *stream);
+
+/* out = (in ? in : 0) + coef * mask * (sa * A[z,x,y] + sb * B[t,l,x/r,y/r]),
+ * coef = coef_host * (coef_dev ? *coef_dev : 1); mask (nZ,X,Y) optional (NULL = ones).
+ * Broadcast-on-read adjoints: replaces T.T, S.T, D.T (fusion.py:36-42), R.T (fusion.py:78-87),
+ * the weighted sum of fusion.py:423-430 and `r - Ap*alpha` (fusion.py:446); with in=NULL it
+ * writes b - A(x0) (fusion.py:428-435) or the Adam gradient (autograd of fusion.py:226-232,
+ * masked as fusion.py:274-278).  scal[DFX_S_RR] = sum(out^2)  (fusion.py:437,447). */
+int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in, const float *A,
+              const float *B, const float *mask, float sa, float sb, float coef_host,
+              const double *coef_dev, double *scal, double *part, void *stream);
+
+/* u[i] = sum_c u_part[c][i] (i < nZ*X*Y); scal[DFX_S_UU] = sum u^2. */
+int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,
+                 double *part, void *stream);
+/* v[i] = sum_zc v_part[zc][i] (i < nT*nL*Xs*Ys). */
+int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, float *v, void *stream);
+/* scal[slot] = sum_i a[i]^2. */
+int dfx_sqnorm(const float *a, int64_t n, double *scal, int32_t slot, double *part, void *stream);
+/* scal[slot] = w * sum_i mask[i % mask_n] * (a[i] - b[i])^2, mask optional (loss terms,
+ * fusion.py:216-232; squared_l2 fusion.py:12-18). */
+int dfx_sqdiff(const float *a, const float *b, const float *mask, int64_t mask_n, int64_t n, double w,
+               double *scal, int32_t slot, double *part, void *stream);
+
+/* alpha (fusion.py:444): PAP = c1*UU + c2*VV ; ALPHA = RSOLD / (PAP + eps). */
+int dfx_cg_alpha(double *scal, double c1, double c2, double eps, void *stream);
+/* After r was updated (RR valid): RSNEW = RR; NONFINITE += !isfinite(RR) (fusion.py:448);
+ * TOL = |alpha| ||p|| / ||x_new|| (fusion.py:244-252; ||x_new||^2 = XX + 2 alpha XP + alpha^2 PP if
+ * deferred, XXNEW otherwise); BETA = RSNEW/(RSOLD+eps) (fusion.py:455); RSOLD = RSNEW (fusion.py:456);
+ * ITER += 1. */
+int dfx_cg_beta(double *scal, double eps, int32_t deferred, void *stream);
+/* First residual: RSOLD = RR (fusion.py:437). */
+int dfx_cg_start(double *scal, void *stream);
+
+/* y[i] += coef_host*(*coef_dev) * x[i]; scal[DFX_S_XXNEW] = sum(y^2)  (fusion.py:445 stand-alone). */
+int dfx_axpy(float *y, const float *x, int64_t n, float coef_host, const double *coef_dev, double *scal,
+             double *part, void *stream);
+/* y[i] = (mask && mask[i % mask_n] == 0) ? 0 : y[i], then *= coef_host*(coef_dev ? *coef_dev : 1)
+ * (fusion.py:197-199,204-209).  mask has period mask_n (= nZ*X*Y) over the flat index. */
+int dfx_scale(float *y, int64_t n, const float *mask, int64_t mask_n, float coef_host,
+              const double *coef_dev, void *stream);
+/* scal[DFX_S_SUM] = sum_i y[i]  (fusion.py:209 tensor.sum()). */
+int dfx_sum(const float *y, int64_t n, double *scal, double *part, void *stream);
+/* dst[0] = num / src[0]  (device scalars; total_energy / sum, fusion.py:209). */
+int dfx_recip(double *dst, const double *src, double num, void *stream);
+
+/* baseline.py:38-50 in one pass: x[t,l,z,x,y] = coef * up(spc)[t,l,x,y] * zw[z,x,y], up = bilinear
+ * (align_corners = False) upsampling by r, zw = cmos / sum_z cmos (times the cmos mask when
+ * mask_noise, fusion.py:197-198).  coef = coef_host * (coef_dev ? *coef_dev : 1).  If x == NULL
+ * nothing is written (sum only).  scal[DFX_S_SUM] = sum(x). */
+int dfx_baseline_init(const dfx_geom *g, const float *spc, const float *zw, float *x, float coef_host,
+                      const double *coef_dev, double *scal, double *part, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
