@@ -1,0 +1,157 @@
+"""bench.py - FusionCG iterations/s and HBM roofline on MI355X (contract: see task statement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3z16|cells]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one CG iteration (fusion.py:439-456) on synthetic inputs already resident in HBM.
+N = 1: BASELINE.json configs[1] (t256 x l16 x z16 x 128 x 128, r = 4).  N > 1: weak scaling, the
+same 16-plane slab per GPU (nZ = 16 N), z-sharded, one RCCL all-reduce of the spc-sized RD partial
+plus two scalar all-reduces per iteration.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+
+WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
+    "c2": (256, 16, 16, 128, 4),
+    "c3z16": (512, 32, 16, 256, 4),      # 64 GiB / vector: the largest single-GPU anchor of config 3
+    "c3g8": (512, 32, 4, 256, 4),        # config 3 as sharded over 8 GPUs (per-GPU slab)
+    "c4g8": (256, 16, 4, 512, 4),        # config 4 as sharded over 8 GPUs (per-GPU slab)
+    "cells": (64, 16, 20, 128, 4),       # README-like
+    "tiny": (8, 4, 4, 64, 4),
+}
+
+
+def synthetic(n_t, n_l, n_z, xy, r, seed=0):
+    """spc then cmos from one CPU generator, 0.1 + 0.9 U[0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    spc = 0.1 + 0.9 * torch.rand(n_t, n_l, xy // r, xy // r, generator=g)
+    cmos = 0.1 + 0.9 * torch.rand(n_z, xy, xy, generator=g)
+    return spc, cmos
+
+
+def cpu_baseline(n_l, n_z, xy, r, full_n, budget_s=20.0):
+    """The oracle (eager-faithful torch-CPU port of fusion.py:423-456, per-iteration loss included)
+    timed on this host on a bounded sample: same geometry, fewer time bins; scaled 1/N to the
+    full workload.  Reported, never the target."""
+    from oracle import fusion_oracle as O
+    n_t = 16
+    spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
+    w = {"spatial": 0.5, "spectro_temporal": 0.5}
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
+    O.cg(pb, 1)  # warm
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        O.cg(pb, 2)          # each call pays b and r0 once, like a reference call would
+        iters += 2
+        dt = time.perf_counter() - t0
+        if dt > budget_s or iters >= 20:
+            break
+    n_sample = n_t * n_l * n_z * xy * xy
+    its = iters / dt
+    return {"value": its * n_sample / full_n, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/fusion_oracle.cg on t{n_t}xl{n_l}xz{n_z}x{xy}x{xy} (N={n_sample}), {iters} iterations "
+                      f"in {dt:.1f}s incl. b/r0 every 2 iterations = {its:.3f} it/s, scaled by N_sample/N_full"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-defer", action="store_true", help="textbook ordering (x updated with r): 8N words/iter")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--target-blocks", type=int, default=0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+        group = dist.group.WORLD
+
+    from datafusion_amd import FusionCG
+    n_t, n_l, nz_gpu, xy, r = WORKLOADS[a.workload]
+    n_z = nz_gpu * world
+    spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
+    f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
+                 mask_noise=False, total_energy=1, device=dev, seed=42, group=group, defer_x=not a.no_defer,
+                 target_blocks=a.target_blocks)
+    n_local = f.k.N
+    n_total = n_local * world
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    f.start()
+    f.iterate(a.warmup)
+    f.k.timing = {}
+    fence()
+    t0 = time.perf_counter()
+    f.iterate(a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    timing, f.k.timing = f.k.timing, None
+    f.finish()  # raises if the residual ever went non-finite
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
+    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs) for name, evs in timing.items()}
+    sweep_name = "sweep2" if a.no_defer else "sweep1"
+    sweep_ms = kern[sweep_name]
+    sweep_bytes = (3 if a.no_defer else 5) * 4 * n_local          # words the kernel must move
+    ach = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+    its = a.steps / dt
+    out = {
+        "metric": "FusionCG iters/sec + achieved HBM GB/s vs peak, 5D fp32 (t,l,z,x,y), 1-8 GPU",
+        "value": its, "unit": "it/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r}, tol=None, baseline init "
+                               f"({a.workload}; {nz_gpu} z-planes per GPU)", "n_elements": n_total,
+                   "parallelism": f"z-shard x{world}", "x_update": "textbook" if a.no_defer else "deferred",
+                   "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "n_blocks")}},
+        # whole iteration, all GPUs: SURVEY 8(d) prices an iteration at 32 N bytes; this build moves 28 N
+        "hbm_effective_GBps": 32.0 * n_total * its / 1e9,
+        "hbm_effective_frac_of_peak": 32.0 * n_local * its / 1e9 / HBM_PEAK_GBPS,
+        "hbm_moved_GBps": (32.0 if a.no_defer else 28.0) * n_total * its / 1e9,
+        "kernel_ms": kern,
+        "roofline": {"bound": "hbm", "kernel": "k_sweep_fast<XP,16>" if not a.no_defer else "k_sweep_fast<P,16>",
+                     "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                     "traffic": None, "bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms},
+    }
+    if rank == 0:
+        if not a.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n_l, n_z, xy, r, n_total)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

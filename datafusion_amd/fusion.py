@@ -226,6 +226,8 @@ class FusionCG(Fusion):
         self.w1 = self.weights["spatial"]
         self.w2 = self.weights["spectro_temporal"]
         self._r = self._p = None
+        self._pending_x = False
+        self._stopped = False
 
     def _finish_projection(self) -> None:
         """After a sweep that produced u(p), v(p) partials: cross-shard sums + ||v||^2."""
@@ -234,20 +236,21 @@ class FusionCG(Fusion):
         k.sqnorm_v()                                  # VV identical on every rank
         c.sum_(k.scal[cabi.S_UU:cabi.S_XP + 1])       # UU, PP, XX, XP partials
 
-    @torch.no_grad()
-    def __call__(self, max_iterations: int, eps: float = 1e-10, return_numpy: bool = True):
-        k, c = self.k, self.comm
-        n_t, n_l, n_z, r = self.n_times, self.n_lambdas, self.z_dim, self.spatial_increase
+    def _coefs(self):
         # A p = c1 * bcast_{t,l} u(p) + c2 * bcast_{z,block} v(p)   (fusion.py:423-426 with the 1/size
         # factors of the normalised transposes folded in)
-        c1, c2 = float(self.w1) / (n_t * n_l), float(self.w2) / (n_z * r * r)
+        n_t, n_l, n_z, r = self.n_times, self.n_lambdas, self.z_dim, self.spatial_increase
+        return float(self.w1) / (n_t * n_l), float(self.w2) / (n_z * r * r)
+
+    @torch.no_grad()
+    def start(self) -> None:
+        """r0 = b - A(x0), p0 = r0, rsold (fusion.py:428-437), from the current self.x."""
+        k, c = self.k, self.comm
+        c1, c2 = self._coefs()
         if self._r is None:
             self._r, self._p = k.new_vector(), k.new_vector()
         x, rv, pv = self.x, self._r, self._p
-        deferred = self.defer_x
-        history = np.zeros((int(max_iterations), len(self.weights) + 2)) if self.verbose else None
-
-        # r0 = b - A(x0) = c1 bcast(cmos_n - u(x0)) + c2 bcast(spc_n - v(x0))      (fusion.py:428-435)
+        # r0 = c1 bcast(cmos_n - u(x0)) + c2 bcast(spc_n - v(x0))
         self._project(x)
         du = self._cmos_loc - k.u
         dv = self.spc - k.v
@@ -256,35 +259,60 @@ class FusionCG(Fusion):
         k.cg_start()                                                            # rsold (fusion.py:437)
         k.sweep(cabi.SWEEP_PINIT, x, rv, pv)                                    # p = r (fusion.py:436)
         self._finish_projection()
+        self._pending_x = False
+        self._stopped = False
 
-        pending_x = False
-        for i in range(int(max_iterations)):
+    @torch.no_grad()
+    def iterate(self, n_iterations: int, eps: float = 1e-10, history=None) -> None:
+        """`n_iterations` passes of the loop body fusion.py:439-456 (stops early on tolerance).
+        Enqueues kernels only; with tol=None and verbose=False it never synchronises."""
+        k, c = self.k, self.comm
+        c1, c2 = self._coefs()
+        x, rv, pv = self.x, self._r, self._p
+        deferred = self.defer_x
+        for i in range(int(n_iterations)):
+            if self._stopped:
+                break
             self.curr_iter += 1
             k.cg_alpha(c1, c2, eps)                                             # fusion.py:443-444
             if not deferred:
                 k.axpy(x, pv, 1.0, cabi.S_ALPHA)                                # fusion.py:445
                 c.sum_(k.scal[cabi.S_XXNEW:cabi.S_XXNEW + 1])
             else:
-                pending_x = True
+                self._pending_x = True
             k.bcast(rv, rv, k.u, k.v, None, c1, c2, -1.0, cabi.S_ALPHA)         # fusion.py:446-447
             c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
             k.cg_beta(eps, deferred)                                            # rsnew, tol, beta
             if self.tol is not None or self.verbose:
                 s = k.scal.cpu()                                                # one sync, as fusion.py:448
                 assert bool(s[cabi.S_NONFINITE] == 0), "Conjugate gradient diverged"
-                tolerance = float(s[cabi.S_TOL]) if self.tol is not None else None
-                if self.tol is not None and tolerance < self.tol:              # fusion.py:451-453
+                if self.tol is not None and float(s[cabi.S_TOL]) < self.tol:    # fusion.py:451-453
+                    self._stopped = True
                     break
-            if self.verbose:                                                    # fusion.py:458-478
+            if history is not None:                                             # fusion.py:458-478
                 l1, l2 = self.loss()                                            # x is current: defer_x is off
                 history[i] = [float(l1), float(l2), float(l1) + float(l2), float(s[cabi.S_RSNEW])]
             k.sweep(cabi.SWEEP_XP if deferred else cabi.SWEEP_P, x, rv, pv)     # fusion.py:445,455
-            pending_x = False
+            self._pending_x = False
             self._finish_projection()
-        if pending_x:                                   # left the loop by tolerance: x_{i+1} still owed
-            k.axpy(x, pv, 1.0, cabi.S_ALPHA)
+
+    @torch.no_grad()
+    def finish(self) -> None:
+        """Apply an x update still owed (loop left by tolerance) and raise the assertion of
+        fusion.py:448 if any residual norm was not finite."""
+        k = self.k
+        if self._pending_x:
+            k.axpy(self.x, self._p, 1.0, cabi.S_ALPHA)
+            self._pending_x = False
         s = k.scal.cpu()
         assert bool(s[cabi.S_NONFINITE] == 0), "Conjugate gradient diverged"   # fusion.py:448
+
+    @torch.no_grad()
+    def __call__(self, max_iterations: int, eps: float = 1e-10, return_numpy: bool = True):
+        history = np.zeros((int(max_iterations), len(self.weights) + 2)) if self.verbose else None
+        self.start()
+        self.iterate(max_iterations, eps, history)
+        self.finish()
         self.history = history
         return self._result(return_numpy)
 

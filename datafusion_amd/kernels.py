@@ -38,6 +38,7 @@ class HipKernels:
         self._v_own = (torch.empty((n_t, n_l, self.Xs, self.Ys), dtype=torch.float32, device=dev)
                        if self.plan.n_zchunks > 1 else None)
         self.v = self._v_own if self._v_own is not None else self.v_part.view(n_t, n_l, self.Xs, self.Ys)
+        self.timing = None   # bench.py sets a dict: name -> list of (start, end) torch.cuda.Event pairs
 
     # -- helpers --------------------------------------------------------------------------
     def _stream(self):
@@ -45,6 +46,17 @@ class HipKernels:
 
     def _g(self):
         return C.byref(self.geom), C.byref(self.plan)
+
+    def _timed(self, name, fn, *args):
+        """Launch through `fn`; when self.timing is set, bracket it with HIP events on the launch stream."""
+        if self.timing is None:
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.device))
+        rc = fn(*args)
+        e1.record(torch.cuda.current_stream(self.device))
+        self.timing.setdefault(name, []).append((e0, e1))
+        return rc
 
     def slot_ptr(self, slot: int) -> int:
         return self.scal.data_ptr() + 8 * slot
@@ -65,9 +77,9 @@ class HipKernels:
             assert t is None or t.numel() == self.N
         g, pl = self._g()
         s = self._stream()
-        cabi.check(self.lib.dfx_sweep(mode, g, pl, cabi.ptr(x), cabi.ptr(r), cabi.ptr(p), cabi.ptr(self.scal),
-                                      cabi.ptr(self.u_part), cabi.ptr(self.v_part), cabi.ptr(self.part), s),
-                   "dfx_sweep")
+        cabi.check(self._timed(f"sweep{mode}", self.lib.dfx_sweep, mode, g, pl, cabi.ptr(x), cabi.ptr(r), cabi.ptr(p),
+                               cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part),
+                               cabi.ptr(self.part), s), "dfx_sweep")
         cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
                                          cabi.ptr(self.part), s), "dfx_reduce_u")
         if self._v_own is not None:
@@ -85,9 +97,10 @@ class HipKernels:
         assert inp is None or inp.numel() == self.N
         assert mask is None or mask.numel() == self.S
         g, pl = self._g()
-        cabi.check(self.lib.dfx_bcast(g, pl, cabi.ptr(out), cabi.ptr(inp), cabi.ptr(A), cabi.ptr(B), cabi.ptr(mask),
-                                      sa, sb, coef_host, None if coef_slot is None else self.slot_ptr(coef_slot),
-                                      cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_bcast")
+        cabi.check(self._timed("bcast", self.lib.dfx_bcast, g, pl, cabi.ptr(out), cabi.ptr(inp), cabi.ptr(A),
+                               cabi.ptr(B), cabi.ptr(mask), sa, sb, coef_host,
+                               None if coef_slot is None else self.slot_ptr(coef_slot),
+                               cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_bcast")
 
     def axpy(self, y, x, coef_host: float, coef_slot: int | None) -> None:
         """y += coef * x ; XXNEW = ||y||^2."""
