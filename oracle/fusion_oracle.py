@@ -45,14 +45,14 @@ def spread_mean(y: torch.Tensor, size: int, dim: int) -> torch.Tensor:
 def block_sum(x: torch.Tensor, r: int) -> torch.Tensor:
     """R forward (fusion.py:89-98): depthwise ones r x r conv, stride r, on (nT, nL, 1, X, Y)."""
     n_l = x.shape[1]
-    k = torch.ones(n_l, 1, r, r)
+    k = torch.ones(n_l, 1, r, r, dtype=x.dtype)
     return F.conv2d(x.squeeze(2), k, stride=r, groups=n_l, bias=None).unsqueeze(2)
 
 
 def block_spread(y: torch.Tensor, r: int) -> torch.Tensor:
     """R.T (fusion.py:78-87): depthwise transposed conv (block replicate) divided by r^2."""
     n_l = y.shape[1]
-    k = torch.ones(n_l, 1, r, r)
+    k = torch.ones(n_l, 1, r, r, dtype=y.dtype)
     return F.conv_transpose2d(y.squeeze(2), k, stride=r, groups=n_l, bias=None).unsqueeze(2) / r**2
 
 
@@ -271,7 +271,7 @@ def adam(pb: Problem, lr: float, max_iterations: int, non_neg: bool = False) -> 
             with torch.no_grad():
                 x.copy_(x.data.clamp(min=0))
         tol_v = float(tolerance(x.detach(), prev_x)) if pb.tol is not None else None
-        rec = {"spatial_loss": float(l1), "spectro_temporal_loss": float(l2), "tolerance": tol_v}
+        rec = {"spatial_loss": float(l1.detach()), "spectro_temporal_loss": float(l2.detach()), "tolerance": tol_v}
         if grad0 is not None:
             rec["grad"] = grad0
         pb.trace.append(rec)

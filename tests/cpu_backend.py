@@ -1,0 +1,124 @@
+"""CPU stand-in for datafusion_amd.kernels.HipKernels - TEST INFRASTRUCTURE ONLY.
+
+Implements the same small interface with plain torch-CPU ops so that the host logic of
+datafusion_amd.fusion (call order, which scalars/partials are all-reduced when, z-sharding,
+deferred x update, tolerance bookkeeping) can run under gloo in a GPU-less container.  It is
+never importable from the product package."""
+import math
+
+import torch
+
+from datafusion_amd import _cabi as cabi
+
+
+class CpuStandIn:
+    def __init__(self, n_t, n_l, n_z_local, X, Y, r, device, target_blocks=0):
+        self.device = torch.device("cpu")
+        self.shape = (n_t, n_l, n_z_local, X, Y)
+        self.r, self.Xs, self.Ys = r, X // r, Y // r
+        self.M, self.S = n_t * n_l, n_z_local * X * Y
+        self.N = self.M * self.S
+        self.scal = torch.zeros(cabi.NSCAL, dtype=torch.float64)
+        self.u = torch.zeros(n_z_local, X, Y)
+        self.v = torch.zeros(n_t, n_l, self.Xs, self.Ys)
+        self.timing = None
+
+    def new_vector(self):
+        return torch.empty(self.shape)
+
+    def _proj(self, a):
+        n_t, n_l, n_z, X, Y = self.shape
+        self.u.copy_(a.sum((0, 1)))
+        self.v.copy_(a.sum(2).reshape(n_t, n_l, self.Xs, self.r, self.Ys, self.r).sum((3, 5)))
+        self.scal[cabi.S_UU] = (self.u.double() ** 2).sum()
+
+    def sweep(self, mode, x, r=None, p=None):
+        s = self.scal
+        al, be = float(s[cabi.S_ALPHA]), float(s[cabi.S_BETA])
+        if mode == cabi.SWEEP_PROJECT:
+            self._proj(x)
+            s[cabi.S_PP], s[cabi.S_XX], s[cabi.S_XP] = 0.0, (x.double() ** 2).sum(), 0.0
+            return
+        if mode == cabi.SWEEP_XP:
+            x.add_(p, alpha=al)
+            p.mul_(be).add_(r)
+        elif mode == cabi.SWEEP_P:
+            p.mul_(be).add_(r)
+        else:
+            p.copy_(r)
+        self._proj(p)
+        s[cabi.S_PP] = (p.double() ** 2).sum()
+        if mode == cabi.SWEEP_P:
+            s[cabi.S_XX], s[cabi.S_XP] = 0.0, 0.0
+        else:
+            s[cabi.S_XX] = (x.double() ** 2).sum()
+            s[cabi.S_XP] = (x.double() * p.double()).sum()
+
+    def sqnorm_v(self):
+        self.scal[cabi.S_VV] = (self.v.double() ** 2).sum()
+
+    def bcast(self, out, inp, A, B, mask, sa, sb, coef_host, coef_slot):
+        coef = coef_host * (float(self.scal[coef_slot]) if coef_slot is not None else 1.0)
+        n_z, X, Y = self.shape[2:]
+        t = (coef * sa) * A.reshape(1, 1, n_z, X, Y) + (coef * sb) * \
+            B.repeat_interleave(self.r, 2).repeat_interleave(self.r, 3).unsqueeze(2)
+        if mask is not None:
+            t = t * mask.reshape(1, 1, n_z, X, Y)
+        if inp is not None:
+            t = t + inp
+        out.copy_(t)
+        self.scal[cabi.S_RR] = (out.double() ** 2).sum()
+
+    def axpy(self, y, x, coef_host, coef_slot):
+        y.add_(x, alpha=coef_host * (float(self.scal[coef_slot]) if coef_slot is not None else 1.0))
+        self.scal[cabi.S_XXNEW] = (y.double() ** 2).sum()
+
+    def scale(self, y, mask, coef_host, coef_slot):
+        if mask is not None:
+            y.view(self.M, -1)[:, mask.reshape(-1) == 0] = 0.0
+        y.mul_(coef_host * (float(self.scal[coef_slot]) if coef_slot is not None else 1.0))
+
+    def sum(self, y):
+        self.scal[cabi.S_SUM] = y.double().sum()
+
+    def recip(self, dst, src, num):
+        self.scal[dst] = num / self.scal[src]
+
+    def sqdiff(self, a, b, mask, w, slot):
+        d = (a.double() - b.double()) ** 2
+        if mask is not None:
+            d = d.reshape(-1, mask.numel()) * mask.reshape(1, -1).double()
+        self.scal[slot] = w * d.sum()
+
+    def baseline_init(self, spc, zw, x, coef_host, coef_slot):
+        coef = coef_host * (float(self.scal[coef_slot]) if coef_slot is not None else 1.0)
+        X, Y = self.shape[3:]
+        up = torch.nn.functional.interpolate(spc, size=(X, Y), mode="bilinear", align_corners=False)
+        full = coef * up.unsqueeze(2) * zw.unsqueeze(0).unsqueeze(0)
+        self.scal[cabi.S_SUM] = full.double().sum()
+        if x is not None:
+            x.copy_(full)
+
+    def cg_start(self):
+        s = self.scal
+        s[cabi.S_RSOLD] = s[cabi.S_RSNEW] = s[cabi.S_RR]
+        s[cabi.S_ALPHA] = s[cabi.S_BETA] = s[cabi.S_TOL] = s[cabi.S_ITER] = 0.0
+        s[cabi.S_NONFINITE] = 0.0 if math.isfinite(float(s[cabi.S_RR])) else 1.0
+
+    def cg_alpha(self, c1, c2, eps):
+        s = self.scal
+        s[cabi.S_PAP] = c1 * s[cabi.S_UU] + c2 * s[cabi.S_VV]
+        s[cabi.S_ALPHA] = s[cabi.S_RSOLD] / (s[cabi.S_PAP] + eps)
+
+    def cg_beta(self, eps, deferred):
+        s = self.scal
+        rs = float(s[cabi.S_RR])
+        s[cabi.S_RSNEW] = rs
+        if not math.isfinite(rs):
+            s[cabi.S_NONFINITE] += 1.0
+        al, pp = float(s[cabi.S_ALPHA]), float(s[cabi.S_PP])
+        xxn = float(s[cabi.S_XX]) + 2 * al * float(s[cabi.S_XP]) + al * al * pp if deferred else float(s[cabi.S_XXNEW])
+        s[cabi.S_TOL] = abs(al) * math.sqrt(pp) / math.sqrt(xxn) if xxn > 0 else float("nan")
+        s[cabi.S_BETA] = rs / (float(s[cabi.S_RSOLD]) + eps)
+        s[cabi.S_RSOLD] = rs
+        s[cabi.S_ITER] += 1.0

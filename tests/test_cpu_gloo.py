@@ -1,0 +1,84 @@
+"""z-sharded host logic under torch.distributed (gloo, world_size 2) on the CPU stand-in backend:
+the sharded result must equal the single-process oracle on the same inputs."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, case, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from datafusion_amd import FusionAdam, FusionCG, fusion
+    from cpu_backend import CpuStandIn
+    from oracle import fusion_oracle as O
+    fusion.Fusion._backend_cls = CpuStandIn
+    w = {"spatial": 0.3, "spectro_temporal": 0.7}
+    spc, cmos = O.cells_like_inputs(6, 3, 5, 16, 4, seed=1)   # 5 planes over 2 ranks: uneven 3 + 2
+    kw = dict(weights=w, init_type=case["init"], tol=case["tol"], mask_noise=case["mask"], device="cpu",
+              group=dist.group.WORLD, defer_x=case["defer"])
+    if case["method"] == "cg":
+        f = FusionCG(spc, cmos, **kw)
+        x, _, _ = f(case["iters"], return_numpy=False)
+    else:
+        f = FusionAdam(spc, cmos, **kw)
+        x, _, _ = f(lr=1e-7, max_iterations=case["iters"], return_numpy=False)
+    l1, l2 = f.loss()
+    parts = [None] * world
+    dist.all_gather_object(parts, (f.z_range, x.detach().numpy()))
+    if rank == 0:
+        full = np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0])], axis=2)
+        q.put((full, f.curr_iter, float(l1), float(l2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(case, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return out
+
+
+def _oracle(case):
+    sys.path[:0] = [ROOT]
+    from oracle import fusion_oracle as O
+    w = {"spatial": 0.3, "spectro_temporal": 0.7}
+    spc, cmos = O.cells_like_inputs(6, 3, 5, 16, 4, seed=1)
+    pb = O.prepare(spc, cmos, weights=w, init_type=case["init"], tol=case["tol"], mask_noise=case["mask"])
+    x = O.cg(pb, case["iters"]) if case["method"] == "cg" else O.adam(pb, 1e-7, case["iters"])
+    l1, l2 = O.loss(pb)
+    return O, x, pb.curr_iter, float(l1), float(l2)
+
+
+def _check(case, port):
+    full, it, l1, l2 = _run(case, port)
+    O, x, it_o, l1o, l2o = _oracle(case)
+    assert it == it_o
+    assert O.rel_l2(full, x) <= 2e-5
+    assert np.allclose([l1, l2], [l1o, l2o], rtol=2e-3, atol=1e-14)
+
+
+def test_gloo_cg_deferred_masked():
+    _check(dict(method="cg", init="baseline", tol=None, mask=True, defer=True, iters=8), 29611)
+
+
+def test_gloo_cg_textbook_tolerance_break_random_init():
+    _check(dict(method="cg", init="random", tol=3e-3, mask=False, defer=False, iters=30), 29612)
+
+
+def test_gloo_adam():
+    _check(dict(method="adam", init="baseline", tol=None, mask=True, defer=True, iters=4), 29613)

@@ -1,0 +1,260 @@
+"""CPU suite (-m "not gpu"): oracle vs the reference-generated goldens, the collapsed fp64 oracle,
+the C ABI surface, the launch planner and the host logic of FusionCG/FusionAdam driven through a
+CPU stand-in backend (single process here; gloo world_size 2 in test_cpu_gloo.py)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def W(g):
+    return {"spatial": float(g["w1"]), "spectro_temporal": float(g["w2"])}
+
+
+CG_CASES = [
+    ("cg_t8l4z4_32_r4", [1, 5, 20], {}),
+    ("cg_t6l5z3_24_r4", [1, 20], {}),
+    ("cg_t4l3z2_16_r2", [20], {}),
+    ("cg_t4l2z3_32_r8", [20], {}),
+    ("cg_t3l2z5_64_r4_w28", [10], {}),
+    ("cg_cells_t8l4z5_32_mask", [10], {"mask_noise": True}),
+    ("cg_cells_t8l4z5_32_e7", [10], {"total_energy": 7.0}),
+]
+
+
+# ---------------------------------------------------------------- oracle pinned by the goldens
+@pytest.mark.parametrize("name,iters,kw", CG_CASES)
+def test_oracle_reproduces_reference_cg(golden, name, iters, kw):
+    g = golden(name)
+    for k in iters:
+        pb = O.prepare(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, **kw)
+        assert O.rel_l2(pb.x, g["x0"]) <= 1e-7
+        assert np.array_equal(pb.spc_mask.numpy(), g["spc_mask"])
+        assert np.array_equal(pb.cmos_mask.numpy(), g["cmos_mask"])
+        x = O.cg(pb, k)
+        assert O.rel_l2(x, g[f"x_{k}"]) <= 1e-6
+    rs = np.array([t["rsnew"] for t in pb.trace])
+    assert np.allclose(rs, g["hist"][: len(rs), 3], rtol=1e-4)
+
+
+def test_oracle_tolerance_random_zeros_baseline_adam(golden):
+    g = golden("cg_tol_t8l4z4_32")
+    pb = O.prepare(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=3e-3)
+    x = O.cg(pb, 50)
+    assert pb.curr_iter == int(g["curr_iter"]) and O.rel_l2(x, g["x"]) <= 1e-6
+    g = golden("cg_random_t4l3z3_16")
+    pb = O.prepare(g["spc"], g["cmos"], weights=W(g), init_type="random", tol=None, seed=42)
+    assert O.rel_l2(pb.x, g["x0"]) <= 1e-7
+    assert O.rel_l2(O.cg(pb, 5), g["x_5"]) <= 1e-6
+    pb = O.prepare(g["spc"], g["cmos"], weights=W(g), init_type="zeros", tol=None)
+    with pytest.raises(AssertionError, match="diverged"):
+        O.cg(pb, 3)
+    with pytest.raises(ValueError):
+        O.prepare(g["spc"], g["cmos"], weights=W(g), init_type="nope")
+    g = golden("baseline_t5l3z4_24")
+    xb = O.baseline_init(torch.from_numpy(g["cmos"].astype(np.float32)), torch.from_numpy(g["spc"].astype(np.float32)))
+    assert O.rel_l2(xb, g["x"]) <= 1e-7
+    for name, mask, nn in (("adam_t6l4z3_32", False, False), ("adam_t6l4z3_32_mask_nn", True, True)):
+        g = golden(name)
+        pb = O.prepare(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, mask_noise=mask)
+        x = O.adam(pb, float(g["lr"]), 5, non_neg=nn)
+        assert O.rel_l2(x, g["x_5"]) <= 1e-6
+        assert O.rel_l2(pb.trace[0]["grad"], g["grad0"]) <= 1e-6
+
+
+def test_operator_identities():
+    """<Op x, y> = size <x, Op.T y> for the normalised transposes; A symmetric PSD."""
+    torch.manual_seed(0)
+    spc, cmos = O.synthetic_inputs(4, 3, 5, 16, 4)
+    pb = O.prepare(spc, cmos, weights={"spatial": 0.3, "spectro_temporal": 0.7}, init_type="baseline", tol=None)
+    p, q = torch.randn(pb.dims, dtype=torch.float64), torch.randn(pb.dims, dtype=torch.float64)
+    pb.x = pb.x.double()
+    ap, aq = O.normal_op(pb, p), O.normal_op(pb, q)
+    assert abs(float((ap * q).sum() - (p * aq).sum())) <= 1e-10 * float(ap.norm() * q.norm())
+    assert float((ap * p).sum()) >= 0
+    y = torch.randn(4, 1, 5, 16, 16, dtype=torch.float64)
+    x = torch.randn(4, 3, 5, 16, 16, dtype=torch.float64)
+    lhs = (O.sum_keep(x, 1) * y).sum()
+    rhs = 3 * (x * O.spread_mean(y, 3, 1)).sum()
+    assert abs(float(lhs - rhs)) <= 1e-10 * abs(float(lhs))
+
+
+def test_collapsed_oracle_matches_eager_oracle():
+    """The fp64 small-space CG used to validate shapes no eager restatement fits."""
+    w = {"spatial": 0.4, "spectro_temporal": 0.6}
+    spc, cmos = O.synthetic_inputs(6, 4, 5, 32, 4, seed=2)
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
+    x0 = pb.x.clone()
+    u0, v0 = O.project(pb, x0)
+    x = O.cg(pb, 8, with_loss=False)
+    a, g, alphas, _ = O.collapsed_cg(pb.spc, pb.cmos, u0[0, 0], v0[:, :, 0], pb.dims, 4, 0.4, 0.6, 8)
+    assert O.rel_l2(x, O.expand_small(x0, a, g, 4)) <= 2e-6
+    assert np.allclose(alphas[:3], [t["alpha"] for t in pb.trace[:3]], rtol=1e-4)
+
+
+# ---------------------------------------------------------------- C ABI surface
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "dfx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from datafusion_amd import _cabi as cabi
+    names = _declared_functions()
+    assert len(names) >= 17
+    assert sorted(cabi.SIGNATURES) == names, "ctypes table and include/dfx.h disagree"
+    lib = C.CDLL(cabi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"libdfx.so does not export {n}"
+    assert cabi.lib().dfx_version() == 100
+
+
+def test_header_constants_match_python_mirror():
+    from datafusion_amd import _cabi as cabi
+    src = open(os.path.join(ROOT, "include", "dfx.h")).read()
+    for name in ("RSOLD", "RSNEW", "PAP", "ALPHA", "BETA", "TOL", "UU", "PP", "XX", "XP", "VV", "RR", "XXNEW",
+                 "NONFINITE", "ITER", "SUM", "SCALE", "LOSS1", "LOSS2"):
+        m = re.search(rf"DFX_S_{name}\s*=\s*(\d+)", src)
+        assert m and int(m.group(1)) == getattr(cabi, "S_" + name), name
+    assert int(re.search(r"DFX_NSCAL\s*=\s*(\d+)", src).group(1)) == cabi.NSCAL
+    assert int(re.search(r"#define DFX_NPART\s+(\d+)", src).group(1)) == cabi.NPART
+    for i, name in enumerate(("PROJECT", "XP", "P", "PINIT")):
+        assert int(re.search(rf"DFX_SWEEP_{name}\s*=\s*(\d+)", src).group(1)) == i
+
+
+@pytest.mark.parametrize("dims,fast", [((256, 16, 16, 128, 128, 4), 1), ((512, 32, 4, 256, 256, 4), 1),
+                                       ((64, 16, 20, 128, 128, 4), 1), ((8, 4, 4, 32, 32, 4), 0),
+                                       ((4, 3, 2, 16, 16, 2), 0), ((3, 2, 11, 64, 128, 4), 1)])
+def test_planner_covers_geometry(dims, fast):
+    """dfx_plan_make is host-only code: runs without a GPU."""
+    from datafusion_amd import _cabi as cabi
+    g, p = cabi.Geom(*dims, 0), cabi.Plan()
+    assert cabi.lib().dfx_plan_make(C.byref(g), 0, C.byref(p)) == 0
+    n_t, n_l, n_z, X, Y, r = dims
+    assert p.fast == fast
+    if fast:
+        assert p.zc * p.n_zchunks >= n_z and p.steps * p.n_chunks >= n_t * n_l
+        assert (p.n_chunks - 1) * p.steps < n_t * n_l and (p.n_zchunks - 1) * p.zc < n_z
+    else:
+        assert p.n_chunks == 1 and p.n_zchunks == 1
+    assert p.u_part_elems == p.n_chunks * n_z * X * Y
+    assert p.v_part_elems == p.n_zchunks * n_t * n_l * (X // r) * (Y // r)
+    assert p.part_elems >= max(p.n_blocks, cabi.EW_MAXBLOCKS) * cabi.NPART
+    if fast:
+        assert p.n_blocks == -(-(X // 4) * (Y // 64) // 4) * p.n_zchunks * p.n_chunks
+
+
+def test_planner_rejects_bad_geometry():
+    from datafusion_amd import _cabi as cabi
+    p = cabi.Plan()
+    for dims in ((0, 1, 1, 4, 4, 4), (2, 2, 2, 10, 8, 4), (2, 2, 2, 8, 8, 0)):
+        assert cabi.lib().dfx_plan_make(C.byref(cabi.Geom(*dims, 0)), 0, C.byref(p)) == cabi_neg(), dims
+    assert b"" != cabi.lib().dfx_last_error()
+
+
+def cabi_neg():
+    return -1
+
+
+def test_product_refuses_cpu_device():
+    from datafusion_amd import FusionCG, _cabi as cabi
+    spc, cmos = O.synthetic_inputs(2, 2, 2, 8, 4)
+    with pytest.raises(cabi.DfxError, match="no CPU path"):
+        FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", device="cpu")
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "datafusion_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert "oracle" not in re.sub(r'""".*?"""', "", open(os.path.join(pkg, fn)).read(), flags=re.S).replace(
+                "# the oracle", ""), fn
+
+
+# ---------------------------------------------------------------- host logic through the CPU stand-in
+@pytest.fixture
+def cpu_backend(monkeypatch):
+    from datafusion_amd import fusion
+    from cpu_backend import CpuStandIn
+    monkeypatch.setattr(fusion.Fusion, "_backend_cls", CpuStandIn)
+
+
+@pytest.mark.parametrize("defer", [True, False])
+@pytest.mark.parametrize("name,iters,kw", CG_CASES[:2] + CG_CASES[5:])
+def test_host_logic_cg_vs_goldens(golden, cpu_backend, name, iters, kw, defer):
+    from datafusion_amd import FusionCG
+    g = golden(name)
+    k = iters[-1]
+    f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu", defer_x=defer, **kw)
+    assert O.rel_l2(f.x, g["x0"]) <= 1e-6
+    x, _, _ = f(k)
+    assert f.curr_iter == k and O.rel_l2(x, g[f"x_{k}"]) <= 2e-5
+
+
+def test_host_logic_tolerance_break_and_reentry(golden, cpu_backend):
+    from datafusion_amd import FusionCG
+    g = golden("cg_tol_t8l4z4_32")
+    for defer in (True, False):
+        f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=3e-3, device="cpu", defer_x=defer)
+        x, _, _ = f(50)
+        assert f.curr_iter == int(g["curr_iter"]) and O.rel_l2(x, g["x"]) <= 2e-5
+    # a second call continues from the current x with fresh r, p (re-entrancy)
+    f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu")
+    f(2)
+    f(3)
+    pb = O.prepare(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None)
+    O.cg(pb, 2)
+    O.cg(pb, 3)
+    assert f.curr_iter == 5 and O.rel_l2(f.x, pb.x) <= 2e-5
+
+
+def test_host_logic_zeros_diverges_and_verbose_history(golden, cpu_backend):
+    from datafusion_amd import FusionCG
+    g = golden("cg_t8l4z4_32_r4")
+    f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="zeros", tol=None, device="cpu")
+    with pytest.raises(AssertionError, match="Conjugate gradient diverged"):
+        f(3)
+    f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu", verbose=True)
+    f(5)
+    assert np.allclose(f.history[:, :3], g["hist"][:5, :3], rtol=2e-3, atol=1e-12)
+
+
+def test_host_logic_adam(golden, cpu_backend):
+    from datafusion_amd import FusionAdam
+    for name, mask, nn in (("adam_t6l4z3_32", False, False), ("adam_t6l4z3_32_mask_nn", True, True)):
+        g = golden(name)
+        f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu", mask_noise=mask)
+        l1, l2 = f.loss()
+        assert np.allclose([float(l1), float(l2)], g["loss0"], rtol=1e-3)
+        x, _, _ = f(lr=float(g["lr"]), max_iterations=5, non_neg=nn)
+        assert O.rel_l2(x, g["x_5"]) <= 2e-5
+
+
+def test_operator_mirrors_match_reference_semantics():
+    from datafusion_amd import SumOperator, SumPoolOperator
+    x = torch.randn(3, 4, 5, 8, 8)
+    for dim in range(3):
+        op = SumOperator(size=x.shape[dim], integral_dim=dim)
+        y = op(x)
+        assert torch.equal(y, O.sum_keep(x, dim)) and op.size == x.shape[dim]
+        assert torch.allclose(op.T(y), O.spread_mean(y, x.shape[dim], dim))
+    R = SumPoolOperator(size=4, channels=4)
+    d = O.sum_keep(x, 2)
+    assert torch.allclose(R(d), O.block_sum(d, 4), atol=1e-5)
+    assert torch.allclose(R.T(R(d)), O.block_spread(O.block_sum(d, 4), 4), atol=1e-5)
+
+
+def test_bench_byte_accounting():
+    """32 N bytes per iteration = 5N (x,r,p read; x,r write) + 3N words; this build's
+    kernels: sweep XP 5N words, bcast 2N words."""
+    n = 256 * 16 * 16 * 128 * 128
+    assert 32 * n == 34359738368
+    assert (5 + 2) * 4 * n == 28 * n
