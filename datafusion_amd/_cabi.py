@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfx.so")
+# DFX_LIB lets tools/tune_kernels.py load a build variant; the product default is the in-tree library
+LIB_PATH = os.environ.get("DFX_LIB") or os.path.join(_HERE, "libdfx.so")
 
 
 class Geom(C.Structure):
@@ -40,6 +41,7 @@ SIGNATURES = {
     "dfx_version": [],
     "dfx_last_error": [],
     "dfx_plan_make": [_G, _i32, _PL],
+    "dfx_plan_make_ex": [_G, _i32, _i32, _i32, _PL],
     "dfx_sweep": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _P],
     "dfx_bcast": [_G, _PL, _P, _P, _P, _P, _P, _f, _f, _f, _P, _P, _P, _P],
     "dfx_reduce_u": [_G, _PL, _P, _P, _P, _P, _P],

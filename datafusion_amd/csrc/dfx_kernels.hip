@@ -20,6 +20,17 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Build-time tuning knobs (tools/tune_kernels.py builds variants; the defaults are the measured best).
+#ifndef DFX_NT
+#define DFX_NT 1          // 1: non-temporal loads/stores for the once-streamed 5-D vectors
+#endif
+#ifndef DFX_MINWAVES
+#define DFX_MINWAVES 1    // __launch_bounds__ 2nd argument (waves per SIMD) of the fast kernels
+#endif
+#ifndef DFX_ZB
+#define DFX_ZB 4          // z planes whose loads are issued together
+#endif
+
 namespace {
 
 thread_local char g_err[256] = "";
@@ -111,11 +122,19 @@ __device__ __forceinline__ void block_store3(double a, double b, double c, doubl
 
 __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
-__device__ __forceinline__ f4 ld4s(const float *p) {  // streamed once: non-temporal
+__device__ __forceinline__ f4 ld4s(const float *p) {  // streamed once
+#if DFX_NT
     return __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+#else
+    return ld4(p);
+#endif
 }
 __device__ __forceinline__ void st4s(float *p, f4 v) {
+#if DFX_NT
     __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+#else
+    st4(p, v);
+#endif
 }
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float dot4(f4 a, f4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
@@ -140,7 +159,7 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
                                             long long voff, float fa, float fb, f4 (&uacc)[ZC], double &dpp,
                                             double &dxx, double &dxp) {
     const int lane = threadIdx.x & 63;
-    constexpr int ZB = ZC < 4 ? ZC : 4;
+    constexpr int ZB = ZC < DFX_ZB ? ZC : DFX_ZB;
     for (int m = m0; m < m1; ++m) {
         const long long base = (long long)m * a.q.S + off;
         f4 s4 = {0.f, 0.f, 0.f, 0.f};
@@ -211,7 +230,7 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
 }
 
 template <int MODE, int ZC>
-__global__ __launch_bounds__(256) void k_sweep_fast(const SweepArgs a) {
+__global__ __launch_bounds__(256, DFX_MINWAVES) void k_sweep_fast(const SweepArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * 4 + wave;
     const int z0 = blockIdx.y * ZC;
@@ -264,7 +283,7 @@ template <int ZC, bool HAS_IN, bool HAS_MASK, bool FULL>
 __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0, int m1, long long off,
                                             long long boff, float cb, const f4 (&av)[ZC], const f4 (&mk)[ZC],
                                             double &drr) {
-    constexpr int ZB = ZC < 4 ? ZC : 4;
+    constexpr int ZB = ZC < DFX_ZB ? ZC : DFX_ZB;
     for (int m = m0; m < m1; ++m) {
         const long long base = (long long)m * a.q.S + off;
         const float b = cb * a.B[boff + (long long)m * a.q.Ps];
@@ -292,7 +311,7 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0
 }
 
 template <int ZC, bool HAS_IN, bool HAS_MASK>
-__global__ __launch_bounds__(256) void k_bcast_fast(const BcastArgs a) {
+__global__ __launch_bounds__(256, DFX_MINWAVES) void k_bcast_fast(const BcastArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * 4 + wave;
     const int z0 = blockIdx.y * ZC;
@@ -682,6 +701,10 @@ int dfx_version(void) { return DFX_VERSION; }
 const char *dfx_last_error(void) { return g_err; }
 
 int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out) {
+    return dfx_plan_make_ex(g, target_blocks, 0, 0, out);
+}
+
+int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, int32_t steps_req, dfx_plan *out) {
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (!out) return fail(DFX_EINVAL, "plan out is NULL");
@@ -690,10 +713,15 @@ int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out) {
     if (fast_ok(q)) {
         out->fast = 1;
         int zc;
-        if (q.nZ % 16 == 0) zc = 16;
-        else if (q.nZ % 8 == 0) zc = 8;
+        // measured on MI355X at t256 x l16 x z16 x 128^2 (tools/tune_kernels.py): zc = 8 beats 16 (which
+        // needs 256 VGPRs + AGPRs) by 5 % and 4 by 3 %; 16 stays available through dfx_plan_make_ex
+        if (q.nZ % 8 == 0) zc = 8;
         else if (q.nZ % 4 == 0 || q.nZ < 8) zc = 4;
         else zc = 8;
+        if (zc_req) {
+            if (zc_req != 4 && zc_req != 8 && zc_req != 16) return fail(DFX_EINVAL, "zc must be 0 (auto), 4, 8 or 16");
+            zc = zc_req;
+        }
         out->zc = zc;
         out->n_zchunks = (q.nZ + zc - 1) / zc;
         const long long groups = (long long)((q.WT + 3) / 4) * out->n_zchunks;
@@ -701,6 +729,7 @@ int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out) {
         const long long lo = q.M < 16 ? q.M : 16, hi = 128;
         if (steps < lo) steps = lo;
         if (steps > hi) steps = hi;
+        if (steps_req > 0) steps = steps_req < q.M ? steps_req : q.M;
         long long n_chunks = (q.M + steps - 1) / steps;
         if (n_chunks > 65535) {  // grid.z limit
             n_chunks = 65535;

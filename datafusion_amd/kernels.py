@@ -15,7 +15,8 @@ from . import _cabi as cabi
 
 
 class HipKernels:
-    def __init__(self, n_t: int, n_l: int, n_z_local: int, X: int, Y: int, r: int, device, target_blocks: int = 0):
+    def __init__(self, n_t: int, n_l: int, n_z_local: int, X: int, Y: int, r: int, device, target_blocks: int = 0,
+                 zc: int = 0, steps: int = 0):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise cabi.DfxError(f"datafusion_amd runs on AMD GPUs only (got device={device!r}); there is no CPU path")
@@ -27,7 +28,8 @@ class HipKernels:
         self.Xs, self.Ys = X // r, Y // r
         self.geom = cabi.Geom(n_t, n_l, n_z_local, X, Y, r, 0)
         self.plan = cabi.Plan()
-        cabi.check(self.lib.dfx_plan_make(C.byref(self.geom), target_blocks, C.byref(self.plan)), "dfx_plan_make")
+        cabi.check(self.lib.dfx_plan_make_ex(C.byref(self.geom), target_blocks, zc, steps, C.byref(self.plan)),
+                   "dfx_plan_make_ex")
         dev = self.device
         self.scal = torch.zeros(cabi.NSCAL, dtype=torch.float64, device=dev)
         self.part = torch.empty(self.plan.part_elems, dtype=torch.float64, device=dev)

@@ -85,6 +85,8 @@ const char *dfx_last_error(void);
 
 /* Choose the launch plan and workspace sizes.  target_blocks <= 0 -> default. */
 int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out);
+/* Same with overrides for tuning: zc in {0 = auto, 4, 8, 16}, steps (0 = auto). */
+int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc, int32_t steps, dfx_plan *out);
 
 /* One pass over the 5-D vectors (replaces, fused: T,S,D,R forward of fusion.py:44-51,89-98 as
  * called from the closure A fusion.py:423-426; the axpy `x + p*alpha` fusion.py:445; the

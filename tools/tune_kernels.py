@@ -1,0 +1,57 @@
+"""Kernel tuning harness (GPU box): times dfx_sweep(XP) and dfx_bcast on one geometry over
+build variants (DFX_LIB=<variant .so>) and plan overrides.  Interleaved rounds in one process per
+library; prints one line per configuration.
+
+    DFX_LIB=build/libdfx_nt1_mw1.so python tools/tune_kernels.py --zc 16,8,4 --steps 32,64
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from datafusion_amd import _cabi as cabi  # noqa: E402
+from datafusion_amd.kernels import HipKernels  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="256,16,16,128,128")
+    ap.add_argument("--zc", default="0")
+    ap.add_argument("--steps", default="0")
+    ap.add_argument("--rounds", type=int, default=8)
+    a = ap.parse_args()
+    n_t, n_l, n_z, X, Y = map(int, a.shape.split(","))
+    dev = "cuda:0"
+    vec = [torch.rand((n_t, n_l, n_z, X, Y), device=dev) for _ in range(3)]
+    cfgs = [(int(z), int(s)) for z in a.zc.split(",") for s in a.steps.split(",")]
+    ks = [HipKernels(n_t, n_l, n_z, X, Y, 4, dev, 0, z, s) for z, s in cfgs]
+    for k in ks:
+        k.scal[cabi.S_ALPHA] = 1e-3
+        k.scal[cabi.S_BETA] = 0.5
+    res = {i: {"sweep": [], "bcast": []} for i in range(len(ks))}
+    for rnd in range(a.rounds + 1):
+        for i, k in enumerate(ks):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            k.sweep(cabi.SWEEP_XP, vec[0], vec[1], vec[2])
+            e[1].record()
+            k.bcast(vec[1], vec[1], k.u, k.v, None, 1e-3, 1e-3, -1.0, cabi.S_ALPHA)
+            e[2].record()
+            torch.cuda.synchronize()
+            if rnd:
+                res[i]["sweep"].append(e[0].elapsed_time(e[1]))
+                res[i]["bcast"].append(e[1].elapsed_time(e[2]))
+    n = vec[0].numel()
+    lib = os.path.basename(cabi.LIB_PATH)
+    for i, k in enumerate(ks):
+        sw, bc = sorted(res[i]["sweep"]), sorted(res[i]["bcast"])
+        ms, mb = sw[len(sw) // 2], bc[len(bc) // 2]
+        print(f"{lib} zc={k.plan.zc} steps={k.plan.steps} blocks={k.plan.n_blocks}: sweep(+reduce_u) med {ms:.3f} ms "
+              f"min {sw[0]:.3f} -> {20 * n / ms / 1e6:.0f} GB/s | bcast med {mb:.3f} min {bc[0]:.3f} -> "
+              f"{8 * n / mb / 1e6:.0f} GB/s | iter {ms + mb:.3f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    main()
