@@ -126,6 +126,15 @@ def main():
     sweep_bytes = (3 if a.no_defer else 5) * 4 * n_local          # words the kernel must move
     ach = sweep_bytes / (sweep_ms * 1e-3) / 1e9
     its = a.steps / dt
+    # HBM bytes per launch from the committed PMC passes of this same command (profiles/): counters cannot be
+    # collected from inside the process being profiled, so the figure is read back, for the workload it was taken on
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pmc["workload"] == a.workload and world == 1 and not a.no_defer:
+            traffic = pmc["k_sweep_fast<1,8>"]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "FusionCG iters/sec + achieved HBM GB/s vs peak, 5D fp32 (t,l,z,x,y), 1-8 GPU",
         "value": its, "unit": "it/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -140,9 +149,9 @@ def main():
         "hbm_effective_frac_of_peak": 32.0 * n_local * its / 1e9 / HBM_PEAK_GBPS,
         "hbm_moved_GBps": (32.0 if a.no_defer else 28.0) * n_total * its / 1e9,
         "kernel_ms": kern,
-        "roofline": {"bound": "hbm", "kernel": "k_sweep_fast<XP,16>" if not a.no_defer else "k_sweep_fast<P,16>",
+        "roofline": {"bound": "hbm", "kernel": f"k_sweep_fast<{'P' if a.no_defer else 'XP'},{f.k.plan.zc}>",
                      "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                     "traffic": None, "bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms},
+                     "traffic": traffic, "bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms},
     }
     if rank == 0:
         if not a.no_cpu and world == 1:
