@@ -28,8 +28,16 @@ class ShardComm:
             self.group = group if group is not True else dist.group.WORLD
             self.size = dist.get_world_size(self.group)
             self.rank = dist.get_rank(self.group)
+            # a gloo group cannot reduce device memory: stage through the host (debug / test set-ups where
+            # several ranks share one GPU; production groups are "nccl" = RCCL and reduce in place)
+            self._stage = dist.get_backend(self.group) == "gloo"
 
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self._stage and t.device.type != "cpu":
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t

@@ -1,0 +1,110 @@
+"""GPU tests at BASELINE.json's full single-GPU size (size-independent checks: fp64 collapsed CG,
+energy conservation, schedule equivalence) and of the z-sharded path with the real HIP kernels
+(two ranks sharing cuda:0, gloo group staged through the host)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import fusion_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+W = {"spatial": 0.5, "spectro_temporal": 0.5}
+
+
+def _gpu_rel_l2_vs_collapsed(x, x0, a, g, r):
+    """|| x - (x0 + B1 a + B2 g) || / || . || in float64 on the GPU, one time bin at a time."""
+    a = a.to(x.device)
+    g = g.to(x.device)
+    num = torch.zeros((), dtype=torch.float64, device=x.device)
+    den = torch.zeros((), dtype=torch.float64, device=x.device)
+    for t in range(x.shape[0]):
+        up = g[t].repeat_interleave(r, 1).repeat_interleave(r, 2)          # (nL, X, Y)
+        ref = x0[t].double() + a[None] + up[:, None]
+        num += ((x[t].double() - ref) ** 2).sum()
+        den += (ref ** 2).sum()
+    return float(torch.sqrt(num / den))
+
+
+def test_c2_full_size_50_iterations_vs_collapsed_fp64():
+    """BASELINE.json configs[1]: t256 x l16 x z16 x 128 x 128, 50 iterations, tol=None."""
+    from datafusion_amd import FusionCG
+    spc, cmos = O.synthetic_inputs(256, 16, 16, 128, 4)
+    f = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV)
+    x0 = f.x.clone()
+    # energy conservation of the initialiser (cells.ipynb check): sum x = sum spc = sum cmos = 1
+    assert abs(float(x0.double().sum()) - 1.0) <= 1e-5
+    f._project(x0)
+    u0, v0 = f.k.u.cpu().clone(), f.k.v.cpu().clone()
+    x, _, _ = f(50, return_numpy=False)
+    assert f.curr_iter == 50
+    a, g, alphas, rs = O.collapsed_cg(f.spc.cpu(), f.cmos.cpu(), u0, v0, f.x_shape, 4, 0.5, 0.5, 50)
+    err = _gpu_rel_l2_vs_collapsed(x, x0, a, g, 4)
+    print(f"C2 50 iterations: rel-L2 vs fp64 collapsed CG = {err:.3e}; rsnew gpu {float(f.k.scal[1]):.4e} fp64 {rs[-1]:.4e}")
+    assert err <= 1e-4
+    # the residual the device tracked follows the fp64 one
+    assert abs(float(f.k.scal[1]) - rs[-1]) <= 0.05 * rs[-1]
+    # the textbook schedule gives the same iterate
+    del x0
+    f2 = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, defer_x=False)
+    x2, _, _ = f2(50, return_numpy=False)
+    d = float(torch.linalg.vector_norm((x2 - x).double().flatten()) / torch.linalg.vector_norm(x.double().flatten()))
+    assert d <= 2e-6, d
+
+
+def test_cells_like_mid_size_vs_oracle_with_tolerance():
+    """Realistic distribution (second generator of SURVEY 8d), README-like call: tol=3e-3."""
+    from datafusion_amd import FusionCG
+    spc, cmos = O.cells_like_inputs(16, 8, 6, 64, 4, seed=4)
+    w = {"spatial": 0.2, "spectro_temporal": 0.8}
+    f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=3e-3, device=DEV)
+    x, _, _ = f(40)
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=3e-3)
+    xo = O.cg(pb, 40, with_loss=False)
+    assert f.curr_iter == pb.curr_iter
+    assert O.rel_l2(x, xo) <= 2e-5
+
+
+def _shard_worker(rank, world, port, q):
+    sys.path[:0] = [ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from datafusion_amd import FusionCG
+    from oracle import fusion_oracle as Or
+    spc, cmos = Or.synthetic_inputs(6, 4, 12, 64, 4, seed=5)     # 12 planes -> 4 per rank (zc = 4)
+    f = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, group=dist.group.WORLD)
+    x, _, _ = f(10, return_numpy=False)
+    l1, l2 = f.loss()
+    parts = [None] * world
+    dist.all_gather_object(parts, (f.z_range, x.cpu().numpy()))
+    if rank == 0:
+        q.put((np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0])], axis=2), float(l1), float(l2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_z_sharded_hip_path_three_ranks_on_one_gpu():
+    from datafusion_amd import FusionCG
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 3, 29631, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    full, l1, l2 = q.get(timeout=110)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    spc, cmos = O.synthetic_inputs(6, 4, 12, 64, 4, seed=5)
+    f = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV)
+    x, _, _ = f(10)
+    assert O.rel_l2(full, x) <= 2e-6          # only the reduction order differs
+    pb = O.prepare(spc, cmos, weights=W, init_type="baseline", tol=None)
+    assert O.rel_l2(full, O.cg(pb, 10, with_loss=False)) <= 2e-5
+    m1, m2 = f.loss()
+    assert np.allclose([l1, l2], [float(m1), float(m2)], rtol=1e-3, atol=1e-16)
