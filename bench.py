@@ -143,7 +143,7 @@ def main():
         "config": {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r}, tol=None, baseline init "
                                f"({a.workload}; {nz_gpu} z-planes per GPU)", "n_elements": n_total,
                    "parallelism": f"z-shard x{world}", "x_update": "textbook" if a.no_defer else "deferred",
-                   "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "n_blocks")}},
+                   "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "cpb", "n_blocks")}},
         # whole iteration, all GPUs: SURVEY 8(d) prices an iteration at 32 N bytes; this build moves 28 N
         "hbm_effective_GBps": 32.0 * n_total * its / 1e9,
         "hbm_effective_frac_of_peak": 32.0 * n_local * its / 1e9 / HBM_PEAK_GBPS,

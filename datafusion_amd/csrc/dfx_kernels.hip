@@ -27,6 +27,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef DFX_MINWAVES
 #define DFX_MINWAVES 1    // __launch_bounds__ 2nd argument (waves per SIMD) of the fast kernels
 #endif
+#ifndef DFX_WAVES
+#define DFX_WAVES 4       // waves per workgroup of the fast kernels (each wave owns one wave tile)
+#endif
+#ifndef DFX_INTERLEAVE
+#define DFX_INTERLEAVE 1  // 1: concurrently running workgroups take ADJACENT slabs (m = i*gz + z): one contiguous
+#endif                    //    moving window in HBM; 0: each workgroup owns a contiguous run of slabs
+#ifndef DFX_BCAST_INFLIGHT
+#define DFX_BCAST_INFLIGHT 8  // float4 loads a lane of k_bcast_fast keeps in flight (slabs per trip = this / zc)
+#endif
 #ifndef DFX_ZB
 #define DFX_ZB 4          // z planes whose loads are issued together
 #endif
@@ -151,16 +160,18 @@ struct SweepArgs {
     float *v_part;
     double *part;
     Geo q;
-    int steps;
+    int steps;     // slabs per u_part chunk (flush interval of the u accumulators)
+    int n_chunks;  // ceil(M / steps)
+    int cpb;       // consecutive chunks one workgroup walks through
 };
 
 template <int MODE, int ZC, bool FULL>
-__device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0, int m1, long long off,
+__device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0, int m1, int ms, long long off,
                                             long long voff, float fa, float fb, f4 (&uacc)[ZC], double &dpp,
                                             double &dxx, double &dxp) {
     const int lane = threadIdx.x & 63;
     constexpr int ZB = ZC < DFX_ZB ? ZC : DFX_ZB;
-    for (int m = m0; m < m1; ++m) {
+    for (int m = m0; m < m1; m += ms) {
         const long long base = (long long)m * a.q.S + off;
         f4 s4 = {0.f, 0.f, 0.f, 0.f};
         float pp = 0.f, xx = 0.f, xp = 0.f;
@@ -230,13 +241,12 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
 }
 
 template <int MODE, int ZC>
-__global__ __launch_bounds__(256, DFX_MINWAVES) void k_sweep_fast(const SweepArgs a) {
+__global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(const SweepArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wt = blockIdx.x * 4 + wave;
+    const int wt = blockIdx.x * DFX_WAVES + wave;
     const int z0 = blockIdx.y * ZC;
     const int zcnt = min(ZC, a.q.nZ - z0);
-    const int m0 = blockIdx.z * a.steps;
-    const int m1 = min(m0 + a.steps, a.q.M);
+    const int gz = gridDim.z, bz = blockIdx.z;
     double dpp = 0, dxx = 0, dxp = 0;
     if (wt < a.q.WT) {  // wave-uniform
         const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
@@ -247,17 +257,29 @@ __global__ __launch_bounds__(256, DFX_MINWAVES) void k_sweep_fast(const SweepArg
             (long long)blockIdx.y * a.q.M * a.q.Ps + (long long)tx * a.q.Ys + ty * 16 + (lane & 15);
         const float fa = (MODE == DFX_SWEEP_XP) ? (float)a.scal[DFX_S_ALPHA] : 0.f;
         const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)a.scal[DFX_S_BETA] : 0.f;
-        f4 uacc[ZC];
+        for (int c = 0; c < a.cpb; ++c) {
+            // the u accumulators are flushed every `steps` slabs: bounds the length of an fp32 running sum
+#if DFX_INTERLEAVE
+            const int m0 = c * a.steps * gz + bz, ms = gz;
+            const int m1 = min((c + 1) * a.steps * gz, a.q.M);
+            const int chunk = c * gz + bz;
+#else
+            const int m0 = (bz * a.cpb + c) * a.steps, ms = 1;
+            const int m1 = min(m0 + a.steps, a.q.M);
+            const int chunk = bz * a.cpb + c;
+#endif
+            f4 uacc[ZC];
 #pragma unroll
-        for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
-        if (zcnt == ZC)
-            sweep_steps<MODE, ZC, true>(a, zcnt, m0, m1, off, voff, fa, fb, uacc, dpp, dxx, dxp);
-        else
-            sweep_steps<MODE, ZC, false>(a, zcnt, m0, m1, off, voff, fa, fb, uacc, dpp, dxx, dxp);
-        float *up = a.u_part + (long long)blockIdx.z * a.q.S + off;
+            for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (zcnt == ZC)
+                sweep_steps<MODE, ZC, true>(a, zcnt, m0, m1, ms, off, voff, fa, fb, uacc, dpp, dxx, dxp);
+            else
+                sweep_steps<MODE, ZC, false>(a, zcnt, m0, m1, ms, off, voff, fa, fb, uacc, dpp, dxx, dxp);
+            float *up = a.u_part + (long long)chunk * a.q.S + off;
 #pragma unroll
-        for (int k = 0; k < ZC; ++k)
-            if (k < zcnt) st4(up + (long long)k * a.q.P, uacc[k]);
+            for (int k = 0; k < ZC; ++k)
+                if (k < zcnt) st4(up + (long long)k * a.q.P, uacc[k]);
+        }
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     block_store3(dpp, dxx, dxp, a.part + bid * DFX_NPART);
@@ -276,48 +298,65 @@ struct BcastArgs {
     double *part;
     float sa, sb, coef_host;
     Geo q;
-    int steps;
+    int steps, n_chunks, cpb;
 };
 
 template <int ZC, bool HAS_IN, bool HAS_MASK, bool FULL>
-__device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0, int m1, long long off,
+__device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0, int m1, int ms, long long off,
                                             long long boff, float cb, const f4 (&av)[ZC], const f4 (&mk)[ZC],
                                             double &drr) {
-    constexpr int ZB = ZC < DFX_ZB ? ZC : DFX_ZB;
-    for (int m = m0; m < m1; ++m) {
-        const long long base = (long long)m * a.q.S + off;
-        const float b = cb * a.B[boff + (long long)m * a.q.Ps];
-        float rr = 0.f;
+    // MU slabs per trip: one wave per SIMD is the fastest residency for these kernels, so the loads in
+    // flight per lane (MU * ZC float4) are what hides HBM latency
+    constexpr int MU = (DFX_BCAST_INFLIGHT / ZC) > 0 ? DFX_BCAST_INFLIGHT / ZC : 1;
+    for (int m = m0; m < m1; m += ms * MU) {
+        float b[MU];
+        f4 iv[MU][ZC];
 #pragma unroll
-        for (int g = 0; g < ZC; g += ZB) {
-            f4 iv[ZB];
-            if (HAS_IN) {
+        for (int u = 0; u < MU; ++u) {
+            const int mm = m + u * ms;
+            if (mm < m1) {
+                b[u] = cb * a.B[boff + (long long)mm * a.q.Ps];
+                if (HAS_IN) {
+                    const long long base = (long long)mm * a.q.S + off;
 #pragma unroll
-                for (int j = 0; j < ZB; ++j)
-                    if (FULL || g + j < zcnt) iv[j] = ld4s(a.in + base + (long long)(g + j) * a.q.P);
-            }
-#pragma unroll
-            for (int j = 0; j < ZB; ++j) {
-                if (FULL || g + j < zcnt) {
-                    f4 o = av[g + j] + (HAS_MASK ? mk[g + j] * b : (f4){b, b, b, b});
-                    if (HAS_IN) o += iv[j];
-                    st4s(a.out + base + (long long)(g + j) * a.q.P, o);
-                    rr += dot4(o, o);
+                    for (int k = 0; k < ZC; ++k)
+                        if (FULL || k < zcnt) iv[u][k] = ld4s(a.in + base + (long long)k * a.q.P);
                 }
             }
         }
-        drr += (double)rr;
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            const int mm = m + u * ms;
+            if (mm < m1) {
+                const long long base = (long long)mm * a.q.S + off;
+                float rr = 0.f;
+#pragma unroll
+                for (int k = 0; k < ZC; ++k) {
+                    if (FULL || k < zcnt) {
+                        f4 o = av[k] + (HAS_MASK ? mk[k] * b[u] : (f4){b[u], b[u], b[u], b[u]});
+                        if (HAS_IN) o += iv[u][k];
+                        st4s(a.out + base + (long long)k * a.q.P, o);
+                        rr += dot4(o, o);
+                    }
+                }
+                drr += (double)rr;
+            }
+        }
     }
 }
 
 template <int ZC, bool HAS_IN, bool HAS_MASK>
-__global__ __launch_bounds__(256, DFX_MINWAVES) void k_bcast_fast(const BcastArgs a) {
+__global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(const BcastArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wt = blockIdx.x * 4 + wave;
+    const int wt = blockIdx.x * DFX_WAVES + wave;
     const int z0 = blockIdx.y * ZC;
     const int zcnt = min(ZC, a.q.nZ - z0);
-    const int m0 = blockIdx.z * a.steps;
-    const int m1 = min(m0 + a.steps, a.q.M);
+#if DFX_INTERLEAVE
+    const int m0 = blockIdx.z, ms = gridDim.z, m1 = a.q.M;
+#else
+    const int m0 = blockIdx.z * a.cpb * a.steps, ms = 1;
+    const int m1 = min(m0 + a.cpb * a.steps, a.q.M);
+#endif
     double drr = 0;
     if (wt < a.q.WT) {
         const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
@@ -341,9 +380,9 @@ __global__ __launch_bounds__(256, DFX_MINWAVES) void k_bcast_fast(const BcastArg
             }
         }
         if (zcnt == ZC)
-            bcast_steps<ZC, HAS_IN, HAS_MASK, true>(a, zcnt, m0, m1, off, boff, cb, av, mk, drr);
+            bcast_steps<ZC, HAS_IN, HAS_MASK, true>(a, zcnt, m0, m1, ms, off, boff, cb, av, mk, drr);
         else
-            bcast_steps<ZC, HAS_IN, HAS_MASK, false>(a, zcnt, m0, m1, off, boff, cb, av, mk, drr);
+            bcast_steps<ZC, HAS_IN, HAS_MASK, false>(a, zcnt, m0, m1, ms, off, boff, cb, av, mk, drr);
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     block_store3(drr, 0.0, 0.0, a.part + bid * DFX_NPART);
@@ -647,10 +686,13 @@ int check_plan(const Geo &q, const dfx_plan *pl) {
     if (pl->fast) {
         if (!fast_ok(q)) return fail(DFX_EPLAN, "fast plan on a geometry that needs the generic path");
         if (pl->zc != 4 && pl->zc != 8 && pl->zc != 16) return fail(DFX_EPLAN, "fast plan: zc must be 4, 8 or 16");
+        if (pl->cpb <= 0 || pl->n_chunks % pl->cpb) return fail(DFX_EPLAN, "plan: n_chunks must be a multiple of cpb");
         if ((long long)pl->zc * pl->n_zchunks < q.nZ || (long long)pl->steps * pl->n_chunks < q.M)
             return fail(DFX_EPLAN, "plan does not cover the geometry");
-        if (pl->n_chunks > 65535 || pl->n_zchunks > 65535) return fail(DFX_EPLAN, "plan grid too large");
-        const long long nb = (long long)((q.WT + 3) / 4) * pl->n_zchunks * pl->n_chunks;
+        if (pl->n_zchunks > 65535) return fail(DFX_EPLAN, "plan grid too large");
+        const long long gz = (pl->n_chunks + pl->cpb - 1) / pl->cpb;
+        if (gz > 65535) return fail(DFX_EPLAN, "plan grid too large");
+        const long long nb = (long long)((q.WT + DFX_WAVES - 1) / DFX_WAVES) * pl->n_zchunks * gz;
         if (nb != pl->n_blocks) return fail(DFX_EPLAN, "plan n_blocks inconsistent");
     } else if (pl->n_chunks != 1 || pl->n_zchunks != 1) {
         return fail(DFX_EPLAN, "generic plan must have n_chunks = n_zchunks = 1");
@@ -662,7 +704,7 @@ bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <int MODE>
 int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
-    dim3 grid((a.q.WT + 3) / 4, pl->n_zchunks, pl->n_chunks), block(256);
+    dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
     switch (pl->zc) {
         case 4: hipLaunchKernelGGL((k_sweep_fast<MODE, 4>), grid, block, 0, st, a); break;
         case 8: hipLaunchKernelGGL((k_sweep_fast<MODE, 8>), grid, block, 0, st, a); break;
@@ -674,7 +716,7 @@ int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
 
 template <bool HAS_IN, bool HAS_MASK>
 int launch_bcast_fast(const BcastArgs &a, const dfx_plan *pl, hipStream_t st) {
-    dim3 grid((a.q.WT + 3) / 4, pl->n_zchunks, pl->n_chunks), block(256);
+    dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
     switch (pl->zc) {
         case 4: hipLaunchKernelGGL((k_bcast_fast<4, HAS_IN, HAS_MASK>), grid, block, 0, st, a); break;
         case 8: hipLaunchKernelGGL((k_bcast_fast<8, HAS_IN, HAS_MASK>), grid, block, 0, st, a); break;
@@ -709,7 +751,6 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
     if (int rc = make_geo(g, &q)) return rc;
     if (!out) return fail(DFX_EINVAL, "plan out is NULL");
     memset(out, 0, sizeof(*out));
-    if (target_blocks <= 0) target_blocks = 2048;
     if (fast_ok(q)) {
         out->fast = 1;
         int zc;
@@ -724,21 +765,41 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         }
         out->zc = zc;
         out->n_zchunks = (q.nZ + zc - 1) / zc;
-        const long long groups = (long long)((q.WT + 3) / 4) * out->n_zchunks;
-        long long steps = ((long long)q.M * groups + target_blocks - 1) / target_blocks;
-        const long long lo = q.M < 16 ? q.M : 16, hi = 128;
-        if (steps < lo) steps = lo;
-        if (steps > hi) steps = hi;
-        if (steps_req > 0) steps = steps_req < q.M ? steps_req : q.M;
+        // Grid sizing.  Measured on MI355X (tools/tune_kernels.py): these kernels stream fastest with ONE
+        // 4-wave workgroup per CU walking a long run of slabs (C2: 6.0 TB/s at 256 workgroups vs 5.5 at 2048:
+        // fewer concurrent DRAM streams), so the default target is the CU count.  `steps` only sets how often
+        // the fp32 u accumulators are flushed to u_part (accuracy + 2N/steps words of extra traffic).
+        const long long groups = (long long)((q.WT + DFX_WAVES - 1) / DFX_WAVES) * out->n_zchunks;
+        long long steps = steps_req > 0 ? steps_req : 64;
+        if (steps > q.M) steps = q.M;
         long long n_chunks = (q.M + steps - 1) / steps;
-        if (n_chunks > 65535) {  // grid.z limit
-            n_chunks = 65535;
-            steps = (q.M + n_chunks - 1) / n_chunks;
-            n_chunks = (q.M + steps - 1) / steps;
+        if (target_blocks <= 0) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+            (void)hipGetLastError();
+            target_blocks = cus;
         }
+        // workgroups along the slab axis: fill whole "rounds" of one workgroup per CU (80 tile groups on 256 CUs:
+        // gz = 3 or 6 -> 240 / 480 workgroups, not 4 -> 320, which leaves a quarter-full second round)
+        long long gz = 1;
+        {
+            double best = -1.0;
+            const long long gz_hi = (4LL * target_blocks + groups - 1) / groups;
+            for (long long c = 1; c <= gz_hi && c <= n_chunks && c <= 65535; ++c) {
+                const long long nb = groups * c, rounds = (nb + target_blocks - 1) / target_blocks;
+                const double score = (double)nb / (double)(rounds * target_blocks) - 0.02 * (double)(rounds - 1);
+                if (score > best + 1e-9) best = score, gz = c;
+            }
+        }
+        long long cpb = (n_chunks + gz - 1) / gz;
+        gz = (n_chunks + cpb - 1) / cpb;
+        n_chunks = cpb * gz;   // u_part rows; with interleaving the last ones may cover fewer (or no) slabs
         out->steps = (int)steps;
         out->n_chunks = (int)n_chunks;
-        const long long nb = groups * n_chunks;
+        out->cpb = (int)cpb;
+        const long long nb = groups * gz;
         if (nb > 0x7fffffffLL) return fail(DFX_EINVAL, "too many workgroups");
         out->n_blocks = (int)nb;
     } else {
@@ -747,6 +808,7 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         out->n_zchunks = 1;
         out->steps = q.M;
         out->n_chunks = 1;
+        out->cpb = 1;
         out->n_blocks = ew_blocks(q.N, 4);
     }
     out->u_part_elems = (long long)out->n_chunks * q.S;
@@ -769,7 +831,7 @@ int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, con
     if (pl->fast) {
         if (!aligned16(x) || !aligned16(r) || !aligned16(p) || !aligned16(u_part))
             return fail(DFX_EALIGN, "dfx_sweep: x, r, p, u_part must be 16-byte aligned");
-        SweepArgs a{x, r, p, scal, u_part, v_part, part, q, pl->steps};
+        SweepArgs a{x, r, p, scal, u_part, v_part, part, q, pl->steps, pl->n_chunks, pl->cpb};
         int rc;
         switch (mode) {
             case DFX_SWEEP_PROJECT: rc = launch_sweep_fast<DFX_SWEEP_PROJECT>(a, pl, st); break;
@@ -815,7 +877,7 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
     if (int rc = check_plan(q, pl)) return rc;
     if (!out || !A || !B || !scal || !part) return fail(DFX_EINVAL, "dfx_bcast: NULL buffer");
     hipStream_t st = (hipStream_t)stream;
-    BcastArgs a{out, in, A, B, mask, coef_dev, part, sa, sb, coef_host, q, pl->steps};
+    BcastArgs a{out, in, A, B, mask, coef_dev, part, sa, sb, coef_host, q, pl->steps, pl->n_chunks, pl->cpb};
     int n_rows;
     if (pl->fast) {
         if (!aligned16(out) || !aligned16(in) || !aligned16(A) || !aligned16(mask))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 100
+#define DFX_VERSION 101
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -43,9 +43,11 @@ typedef struct dfx_plan {
     int32_t fast;
     int32_t zc;          /* z planes a workgroup keeps in registers */
     int32_t n_zchunks;   /* ceil(nZ / zc) */
-    int32_t steps;       /* (t,lambda) slabs per workgroup */
+    int32_t steps;       /* (t,lambda) slabs per u_part chunk (flush interval of the fp32 u sums) */
     int32_t n_chunks;    /* ceil(nT*nL / steps) */
+    int32_t cpb;         /* consecutive chunks one workgroup walks through */
     int32_t n_blocks;    /* workgroups per sweep / bcast launch */
+    int32_t pad_;
     int64_t u_part_elems;    /* floats: n_chunks * nZ*X*Y */
     int64_t v_part_elems;    /* floats: n_zchunks * nT*nL*Xs*Ys */
     int64_t part_elems;      /* doubles: max(n_blocks, DFX_EW_MAXBLOCKS) * DFX_NPART */
@@ -83,7 +85,8 @@ enum {
 int dfx_version(void);
 const char *dfx_last_error(void);
 
-/* Choose the launch plan and workspace sizes.  target_blocks <= 0 -> default. */
+/* Choose the launch plan and workspace sizes.  target_blocks <= 0 -> default (one workgroup per CU of the
+ * current device; 256 when no device is visible). */
 int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out);
 /* Same with overrides for tuning: zc in {0 = auto, 4, 8, 16}, steps (0 = auto). */
 int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc, int32_t steps, dfx_plan *out);

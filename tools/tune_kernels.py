@@ -20,13 +20,36 @@ def main():
     ap.add_argument("--shape", default="256,16,16,128,128")
     ap.add_argument("--zc", default="0")
     ap.add_argument("--steps", default="0")
+    ap.add_argument("--blocks", default="0", help="target block counts (0 = one per CU)")
     ap.add_argument("--rounds", type=int, default=8)
+    ap.add_argument("--pad", default="-1", help="bytes of skew between x, r, p carved from one buffer (-1: 3 allocations)")
     a = ap.parse_args()
     n_t, n_l, n_z, X, Y = map(int, a.shape.split(","))
     dev = "cuda:0"
-    vec = [torch.rand((n_t, n_l, n_z, X, Y), device=dev) for _ in range(3)]
-    cfgs = [(int(z), int(s)) for z in a.zc.split(",") for s in a.steps.split(",")]
-    ks = [HipKernels(n_t, n_l, n_z, X, Y, 4, dev, 0, z, s) for z, s in cfgs]
+    pads = [int(v) for v in a.pad.split(",")]
+    arena = None
+    if os.environ.get("TUNE_ARENA"):
+        arena = torch.empty(3 * n_t * n_l * n_z * X * Y + 2 * (max(pads) // 4) + 1024, device=dev)
+    for pad in pads:
+        run(a, pad, n_t, n_l, n_z, X, Y, dev, arena)
+
+
+def run(a, pad, n_t, n_l, n_z, X, Y, dev, arena=None):
+    n = n_t * n_l * n_z * X * Y
+    if arena is not None:
+        vec = [arena[i * (n + pad // 4): i * (n + pad // 4) + n].view(n_t, n_l, n_z, X, Y) for i in range(3)]
+        for v in vec:
+            v.uniform_()
+    elif pad < 0:
+        vec = [torch.rand((n_t, n_l, n_z, X, Y), device=dev) for _ in range(3)]
+    else:
+        buf = torch.empty(3 * n + 2 * (pad // 4), device=dev)
+        vec = [buf[i * (n + pad // 4): i * (n + pad // 4) + n].view(n_t, n_l, n_z, X, Y) for i in range(3)]
+        for v in vec:
+            v.uniform_()
+    print("pad", pad, "base addresses", [hex(v.data_ptr()) for v in vec], flush=True)
+    cfgs = [(int(z), int(s), int(b)) for z in a.zc.split(",") for s in a.steps.split(",") for b in a.blocks.split(",")]
+    ks = [HipKernels(n_t, n_l, n_z, X, Y, 4, dev, b, z, s) for z, s, b in cfgs]
     for k in ks:
         k.scal[cabi.S_ALPHA] = 1e-3
         k.scal[cabi.S_BETA] = 0.5
@@ -48,7 +71,9 @@ def main():
     for i, k in enumerate(ks):
         sw, bc = sorted(res[i]["sweep"]), sorted(res[i]["bcast"])
         ms, mb = sw[len(sw) // 2], bc[len(bc) // 2]
-        print(f"{lib} zc={k.plan.zc} steps={k.plan.steps} blocks={k.plan.n_blocks}: sweep(+reduce_u) med {ms:.3f} ms "
+        if os.environ.get("TUNE_VERBOSE"):
+            print("   sweep rounds:", " ".join(f"{t:.2f}" for t in res[i]["sweep"]), flush=True)
+        print(f"{lib} zc={k.plan.zc} steps={k.plan.steps} cpb={k.plan.cpb} blocks={k.plan.n_blocks}: sweep(+reduce_u) med {ms:.3f} ms "
               f"min {sw[0]:.3f} -> {20 * n / ms / 1e6:.0f} GB/s | bcast med {mb:.3f} min {bc[0]:.3f} -> "
               f"{8 * n / mb / 1e6:.0f} GB/s | iter {ms + mb:.3f} ms", flush=True)
 
