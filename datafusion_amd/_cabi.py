@@ -26,7 +26,7 @@ class Plan(C.Structure):
 
 # slots of the device state `scal` (include/dfx.h)
 S_RSOLD, S_RSNEW, S_PAP, S_ALPHA, S_BETA, S_TOL, S_UU, S_PP, S_XX, S_XP, S_VV, S_RR, S_XXNEW, S_NONFINITE, \
-    S_ITER, S_SUM, S_SCALE, S_LOSS1, S_LOSS2 = range(19)
+    S_ITER, S_SUM, S_SCALE, S_LOSS1, S_LOSS2, S_ADAM_DD, S_ADAM_XX = range(21)
 NSCAL = 32
 NPART = 4
 EW_MAXBLOCKS = 2048
@@ -45,6 +45,7 @@ SIGNATURES = {
     "dfx_plan_make_ex": [_G, _i32, _i32, _i32, _PL],
     "dfx_sweep": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _P],
     "dfx_bcast": [_G, _PL, _P, _P, _P, _P, _P, _f, _f, _f, _P, _P, _P, _P],
+    "dfx_adam_step": [_G, _PL, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _i32, _i32, _P, _P, _P, _P, _P],
     "dfx_reduce_u": [_G, _PL, _P, _P, _P, _P, _P],
     "dfx_reduce_v": [_G, _PL, _P, _P, _P],
     "dfx_sqnorm": [_P, _i64, _P, _i32, _P, _P],

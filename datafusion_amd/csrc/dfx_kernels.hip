@@ -389,6 +389,149 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(con
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused Adam step (fusion.py:324-346 with torch.optim.Adam(amsgrad=False, weight_decay=0)):
+//   g = mask * (A[z,x,y] + B[m,x/4,y/4])        gradient, broadcast on read: never stored in HBM
+//   m1 += (1-b1)(g - m1) ; m2 = b2 m2 + (1-b2) g^2
+//   x -= (lr/bc1) * m1 / (sqrt(m2)/sqrt(bc2) + eps) ; optional clamp(min=0)
+// plus, in the same pass, what the next iteration needs: u(x), v(x), ||dx||^2, ||x||^2.
+// x, m1, m2 read + written: 6N words per iteration.
+// ------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float *x, *m1, *m2;
+    const float *A, *B, *mask;
+    float *u_part, *v_part;
+    double *part;
+    float b1, b2, eps, step_size, inv_sqrt_bc2;
+    int non_neg;
+    Geo q;
+    int steps, cpb;
+};
+
+__device__ __forceinline__ float adam_elem(float x, float g, float &m1, float &m2, const AdamArgs &a) {
+    m1 = m1 + (1.f - a.b1) * (g - m1);                    // exp_avg.lerp_(grad, 1 - beta1)
+    m2 = a.b2 * m2 + (1.f - a.b2) * (g * g);              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = __fsqrt_rn(m2) * a.inv_sqrt_bc2 + a.eps;
+    float xn = x - a.step_size * __fdiv_rn(m1, denom);    // param.addcdiv_(exp_avg, denom, value=-step_size)
+    if (a.non_neg) xn = fmaxf(xn, 0.f);                   // fusion.py:344-346
+    return xn;
+}
+
+__device__ __forceinline__ f4 adam_elem4(f4 x, f4 g, f4 &m1, f4 &m2, const AdamArgs &a) {
+    float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+    float p0 = m1.x, p1 = m1.y, p2 = m1.z, p3 = m1.w;
+    float q0 = m2.x, q1 = m2.y, q2 = m2.z, q3 = m2.w;
+    x0 = adam_elem(x0, g.x, p0, q0, a);
+    x1 = adam_elem(x1, g.y, p1, q1, a);
+    x2 = adam_elem(x2, g.z, p2, q2, a);
+    x3 = adam_elem(x3, g.w, p3, q3, a);
+    m1 = (f4){p0, p1, p2, p3};
+    m2 = (f4){q0, q1, q2, q3};
+    return (f4){x0, x1, x2, x3};
+}
+
+template <int ZC, bool HAS_MASK>
+__global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(const AdamArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = blockIdx.x * DFX_WAVES + wave;
+    const int z0 = blockIdx.y * ZC;
+    const int zcnt = min(ZC, a.q.nZ - z0);
+    const int gz = gridDim.z, bz = blockIdx.z;
+    double ddd = 0, dxx = 0;
+    if (wt < a.q.WT) {
+        const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
+        const int row = tx * 4 + (lane >> 4);
+        const int col = ty * 64 + (lane & 15) * 4;
+        const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
+        const long long boff = (long long)tx * a.q.Ys + ty * 16 + (lane & 15);
+        const long long voff = (long long)blockIdx.y * a.q.M * a.q.Ps + boff;
+        f4 av[ZC], mk[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) {
+            av[k] = (f4){0.f, 0.f, 0.f, 0.f};
+            mk[k] = (f4){1.f, 1.f, 1.f, 1.f};
+            if (k < zcnt) {
+                av[k] = ld4(a.A + off + (long long)k * a.q.P);
+                if (HAS_MASK) mk[k] = ld4(a.mask + off + (long long)k * a.q.P);
+            }
+        }
+        for (int c = 0; c < a.cpb; ++c) {
+            const int m0 = c * a.steps * gz + bz;
+            const int m1e = min((c + 1) * a.steps * gz, a.q.M);
+            f4 uacc[ZC];
+#pragma unroll
+            for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int m = m0; m < m1e; m += gz) {
+                const long long base = (long long)m * a.q.S + off;
+                const float b = a.B[boff + (long long)m * a.q.Ps];
+                f4 xv[ZC], e1[ZC], e2[ZC];
+#pragma unroll
+                for (int k = 0; k < ZC; ++k) {
+                    if (k < zcnt) {
+                        const long long i = base + (long long)k * a.q.P;
+                        xv[k] = ld4s(a.x + i);
+                        e1[k] = ld4s(a.m1 + i);
+                        e2[k] = ld4s(a.m2 + i);
+                    }
+                }
+                f4 s4 = {0.f, 0.f, 0.f, 0.f};
+                float dd = 0.f, xx = 0.f;
+#pragma unroll
+                for (int k = 0; k < ZC; ++k) {
+                    if (k < zcnt) {
+                        const long long i = base + (long long)k * a.q.P;
+                        f4 g = av[k] + (f4){b, b, b, b};
+                        if (HAS_MASK) g *= mk[k];
+                        const f4 xn = adam_elem4(xv[k], g, e1[k], e2[k], a);
+                        st4s(a.x + i, xn);
+                        st4s(a.m1 + i, e1[k]);
+                        st4s(a.m2 + i, e2[k]);
+                        const f4 d = xn - xv[k];
+                        dd += dot4(d, d);
+                        xx += dot4(xn, xn);
+                        uacc[k] += xn;
+                        s4 += xn;
+                    }
+                }
+                float sv = hsum(s4);
+                sv += __shfl_xor(sv, 16);
+                sv += __shfl_xor(sv, 32);
+                if (lane < 16) a.v_part[voff + (long long)m * a.q.Ps] = sv;
+                ddd += (double)dd;
+                dxx += (double)xx;
+            }
+            float *up = a.u_part + (long long)(c * gz + bz) * a.q.S + off;
+#pragma unroll
+            for (int k = 0; k < ZC; ++k)
+                if (k < zcnt) st4(up + (long long)k * a.q.P, uacc[k]);
+        }
+    }
+    const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_store3(ddd, dxx, 0.0, a.part + bid * DFX_NPART);
+}
+
+__global__ __launch_bounds__(256) void k_gen_adam(AdamArgs a) {
+    double ddd = 0, dxx = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.q.N; i += stride) {
+        const long long m = i / a.q.S;
+        const int j = (int)(i - m * a.q.S);
+        const int xy = (int)(j % a.q.P);
+        const int xi = xy / a.q.Y, yi = xy - xi * a.q.Y;
+        float g = a.A[j] + a.B[m * a.q.Ps + (long long)(xi / a.q.r) * a.q.Ys + yi / a.q.r];
+        if (a.mask) g *= a.mask[j];
+        const float xo = a.x[i];
+        float e1 = a.m1[i], e2 = a.m2[i];
+        const float xn = adam_elem(xo, g, e1, e2, a);
+        a.x[i] = xn;
+        a.m1[i] = e1;
+        a.m2[i] = e2;
+        ddd += (double)((xn - xo) * (xn - xo));
+        dxx += (double)(xn * xn);
+    }
+    block_store3(ddd, dxx, 0.0, a.part + (long long)blockIdx.x * DFX_NPART);
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic (any r, X, Y) kernels: element-wise pass + two projection passes.
 // ------------------------------------------------------------------------------------------
 template <int MODE>
@@ -895,6 +1038,54 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
         DFX_LAUNCH_CHECK("dfx_bcast(generic)");
     }
     return fold(part, n_rows, 1, scal + DFX_S_RR, 1.0, st);
+}
+
+int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, float *m2, const float *A,
+                  const float *B, const float *mask, double lr, double beta1, double beta2, double eps, int32_t step,
+                  int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (int rc = check_plan(q, pl)) return rc;
+    if (!x || !m1 || !m2 || !A || !B || !scal || !u_part || !v_part || !part)
+        return fail(DFX_EINVAL, "dfx_adam_step: NULL buffer");
+    if (step < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1))
+        return fail(DFX_EINVAL, "dfx_adam_step: step >= 1 and betas in [0, 1) required");
+    hipStream_t st = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamArgs a{x, m1, m2, A, B, mask, u_part, v_part, part, (float)beta1, (float)beta2, (float)eps,
+               (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), non_neg ? 1 : 0, q, pl->steps, pl->cpb};
+    int n_rows;
+    if (pl->fast) {
+        if (!aligned16(x) || !aligned16(m1) || !aligned16(m2) || !aligned16(A) || !aligned16(mask) || !aligned16(u_part))
+            return fail(DFX_EALIGN, "dfx_adam_step: x, m1, m2, A, mask, u_part must be 16-byte aligned");
+        dim3 grid((q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb),
+            block(64 * DFX_WAVES);
+        if (mask) {
+            switch (pl->zc) {
+                case 4: hipLaunchKernelGGL((k_adam_fast<4, true>), grid, block, 0, st, a); break;
+                case 8: hipLaunchKernelGGL((k_adam_fast<8, true>), grid, block, 0, st, a); break;
+                default: return fail(DFX_EPLAN, "dfx_adam_step: zc must be 4 or 8");
+            }
+        } else {
+            switch (pl->zc) {
+                case 4: hipLaunchKernelGGL((k_adam_fast<4, false>), grid, block, 0, st, a); break;
+                case 8: hipLaunchKernelGGL((k_adam_fast<8, false>), grid, block, 0, st, a); break;
+                default: return fail(DFX_EPLAN, "dfx_adam_step: zc must be 4 or 8 (16 would spill)");
+            }
+        }
+        DFX_LAUNCH_CHECK("dfx_adam_step(fast)");
+        n_rows = pl->n_blocks;
+    } else {
+        n_rows = pl->n_blocks;
+        hipLaunchKernelGGL(k_gen_adam, dim3(n_rows), dim3(256), 0, st, a);
+        DFX_LAUNCH_CHECK("dfx_adam_step(generic)");
+        hipLaunchKernelGGL(k_gen_proj_u, dim3(ew_blocks(q.S, 1)), dim3(256), 0, st, (const float *)x, u_part, q);
+        DFX_LAUNCH_CHECK("dfx_adam_step(generic u)");
+        hipLaunchKernelGGL(k_gen_proj_v, dim3(ew_blocks((long long)q.M * q.Ps, 1)), dim3(256), 0, st, (const float *)x,
+                           v_part, q);
+        DFX_LAUNCH_CHECK("dfx_adam_step(generic v)");
+    }
+    return fold(part, n_rows, 2, scal + DFX_S_ADAM_DD, 1.0, st);   // (DD, XX) -> consecutive slots
 }
 
 int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,

@@ -350,7 +350,20 @@ class _FusionLossFn(torch.autograd.Function):
 
 
 class FusionAdam(Fusion):
-    """Adam + backprop variant (fusion.py:295-386)."""
+    """Adam + backprop variant (fusion.py:295-386).
+
+    fused=True (default): one dfx_adam_step pass per iteration does the gradient (broadcast on read,
+    never stored), torch.optim.Adam's update, the optional clamp, ||x - prev_x||, ||x|| and the next
+    iteration's projections: 6N words per iteration.  fused=False: the reference's structure -
+    loss() as a custom torch.autograd.Function over the same HIP kernels, loss.backward(),
+    torch.optim.Adam.step()."""
+
+    def __init__(self, *args, fused: bool = True, betas=(0.9, 0.999), adam_eps: float = 1e-8, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.fused = fused
+        self.betas, self.adam_eps = betas, adam_eps
+        self._m1 = self._m2 = None
+        self._adam_step = 0
 
     def loss_autograd(self, mask_grad: bool = False):
         return _FusionLossFn.apply(self.x, self, mask_grad)
@@ -358,7 +371,49 @@ class FusionAdam(Fusion):
     def __call__(self, lr: float, max_iterations: int, non_neg: bool = False, return_numpy: bool = True):
         history = np.zeros((max_iterations, len(self.weights) + 1)) if self.verbose else None
         self.x = torch.nn.Parameter(self.x, requires_grad=True)                 # fusion.py:324-325
-        optimizer = torch.optim.Adam([self.x], lr=lr, amsgrad=False)
+        if self.fused:
+            self._run_fused(lr, max_iterations, non_neg, history)
+        else:
+            self._run_autograd(lr, max_iterations, non_neg, history)
+        self.history = history
+        return self._result(return_numpy)
+
+    @torch.no_grad()
+    def _run_fused(self, lr, max_iterations, non_neg, history):
+        k, c = self.k, self.comm
+        w1, w2 = float(self.weights["spatial"]), float(self.weights["spectro_temporal"])
+        x = self.x.data
+        # a fresh optimizer per call, like fusion.py:325
+        self._m1 = torch.zeros_like(x)
+        self._m2 = torch.zeros_like(x)
+        self._adam_step = 0
+        self._project(x)                                   # u(x), v(x) for the first loss / gradient
+        for i in range(max_iterations):
+            self.curr_iter += 1
+            l1, l2 = self._losses_from_uv()                                     # fusion.py:332
+            # d loss / d u and d loss / d v (autograd of fusion.py:216-232), small arrays
+            A = (-2.0 * w1) * (self._cmos_loc - k.u)
+            B = (-2.0 * w2) * (self.spc - k.v)
+            if self.mask_noise:
+                A = A * self._cmask_loc
+                B = B * self._smask_f
+            self._adam_step += 1
+            k.adam_step(x, self._m1, self._m2, A.contiguous(), B.contiguous(),
+                        self._cmask_loc if self.mask_noise else None,                  # fusion.py:274-278
+                        lr, self.betas[0], self.betas[1], self.adam_eps, self._adam_step, non_neg)
+            c.sum_(k.v)
+            tolerance = None
+            if self.tol is not None:                                            # fusion.py:348
+                d = k.scal[cabi.S_ADAM_DD:cabi.S_ADAM_XX + 1].clone()
+                c.sum_(d)
+                tolerance = float(torch.sqrt(d[0] / d[1]))
+            if tolerance is not None and tolerance < self.tol:                  # fusion.py:357-358
+                break
+            if history is not None:
+                history[i] = [float(l1), float(l2), float(l1) + float(l2)]
+
+    def _run_autograd(self, lr, max_iterations, non_neg, history):
+        optimizer = torch.optim.Adam([self.x], lr=lr, betas=self.betas, eps=self.adam_eps, amsgrad=False)
         for i in range(max_iterations):
             self.curr_iter += 1
             prev_x = self.x.detach().clone() if self.tol is not None else None
@@ -379,7 +434,5 @@ class FusionAdam(Fusion):
                     tolerance = float(torch.sqrt(d[0] / d[1]))
             if tolerance is not None and tolerance < self.tol:
                 break
-            if self.verbose:
+            if history is not None:
                 history[i] = [float(spatial_loss), float(spectro_temporal_loss), float(loss)]
-        self.history = history
-        return self._result(return_numpy)

@@ -87,6 +87,23 @@ class HipKernels:
         if self._v_own is not None:
             cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), s), "dfx_reduce_v")
 
+    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step: int, non_neg: bool) -> None:
+        """One fused Adam iteration: x, m1, m2 in place; u(x_new) -> self.u, local v partial -> self.v;
+        ADAM_DD = ||dx||^2, ADAM_XX = ||x_new||^2."""
+        self._chk(x, m1, m2, A, B, mask)
+        assert x.numel() == m1.numel() == m2.numel() == self.N
+        assert A.numel() == self.S and B.numel() == self.M * self.Xs * self.Ys and (mask is None or mask.numel() == self.S)
+        g, pl = self._g()
+        s = self._stream()
+        cabi.check(self._timed("adam", self.lib.dfx_adam_step, g, pl, cabi.ptr(x), cabi.ptr(m1), cabi.ptr(m2),
+                               cabi.ptr(A), cabi.ptr(B), cabi.ptr(mask), lr, beta1, beta2, eps, step, int(non_neg),
+                               cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part),
+                               cabi.ptr(self.part), s), "dfx_adam_step")
+        cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
+                                         cabi.ptr(self.part), s), "dfx_reduce_u")
+        if self._v_own is not None:
+            cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), s), "dfx_reduce_v")
+
     def sqnorm_v(self) -> None:
         """VV = ||v||^2 (call after the cross-shard sum of v)."""
         cabi.check(self.lib.dfx_sqnorm(cabi.ptr(self.v), self.v.numel(), cabi.ptr(self.scal), cabi.S_VV,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 101
+#define DFX_VERSION 102
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -69,6 +69,8 @@ enum {
     DFX_S_SUM = 15, /* plain sum (dfx_sum, dfx_baseline_init)                         */
     DFX_S_SCALE = 16, /* dfx_recip output by convention                               */
     DFX_S_LOSS1 = 17, DFX_S_LOSS2 = 18, /* dfx_sqdiff outputs by convention           */
+    DFX_S_ADAM_DD = 19, /* ||x_new - x_old||^2 of the last dfx_adam_step              */
+    DFX_S_ADAM_XX = 20, /* ||x_new||^2 of the last dfx_adam_step                      */
     DFX_NSCAL = 32
 };
 #define DFX_NPART 4          /* doubles per workgroup row of `part` */
@@ -108,6 +110,17 @@ int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, con
 int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in, const float *A,
               const float *B, const float *mask, float sa, float sb, float coef_host,
               const double *coef_dev, double *scal, double *part, void *stream);
+
+/* One fused Adam iteration on x (replaces optimizer.step() of fusion.py:324-346 with
+ * torch.optim.Adam(lr, betas, eps, amsgrad=False, weight_decay=0), the materialised gradient of
+ * loss.backward() fusion.py:338, the gradient mask fusion.py:274-278, the clamp fusion.py:344-346, the
+ * clone + norms of fusion.py:329,348 and the next iteration's T,S,D,R forward fusion.py:226-232):
+ *   g = mask * (A[z,x,y] + B[t,l,x/r,y/r]);  m1, m2, x updated in place (6N words);
+ *   u_part, v_part <- projections of the NEW x;  scal[ADAM_DD] = ||dx||^2, scal[ADAM_XX] = ||x||^2.
+ * `step` is the 1-based Adam step count (bias corrections are computed on the host in double). */
+int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, float *m2, const float *A,
+                  const float *B, const float *mask, double lr, double beta1, double beta2, double eps, int32_t step,
+                  int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream);
 
 /* u[i] = sum_c u_part[c][i] (i < nZ*X*Y); scal[DFX_S_UU] = sum u^2. */
 int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,

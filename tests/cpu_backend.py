@@ -54,6 +54,22 @@ class CpuStandIn:
             s[cabi.S_XX] = (x.double() ** 2).sum()
             s[cabi.S_XP] = (x.double() * p.double()).sum()
 
+    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg):
+        n_z, X, Y = self.shape[2:]
+        g = A.reshape(1, 1, n_z, X, Y) + B.repeat_interleave(self.r, 2).repeat_interleave(self.r, 3).unsqueeze(2)
+        if mask is not None:
+            g = g * mask.reshape(1, 1, n_z, X, Y)
+        x_old = x.clone()
+        m1.lerp_(g, 1 - beta1)
+        m2.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+        x.addcdiv_(m1, (m2.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+        if non_neg:
+            x.clamp_(min=0)
+        self._proj(x)
+        self.scal[cabi.S_ADAM_DD] = ((x - x_old).double() ** 2).sum()
+        self.scal[cabi.S_ADAM_XX] = (x.double() ** 2).sum()
+
     def sqnorm_v(self):
         self.scal[cabi.S_VV] = (self.v.double() ** 2).sum()
 

@@ -28,7 +28,7 @@ def _worker(rank, world, port, case, q):
         f = FusionCG(spc, cmos, **kw)
         x, _, _ = f(case["iters"], return_numpy=False)
     else:
-        f = FusionAdam(spc, cmos, **kw)
+        f = FusionAdam(spc, cmos, fused=case.get("fused", True), **kw)
         x, _, _ = f(lr=1e-7, max_iterations=case["iters"], return_numpy=False)
     l1, l2 = f.loss()
     parts = [None] * world
@@ -80,5 +80,9 @@ def test_gloo_cg_textbook_tolerance_break_random_init():
     _check(dict(method="cg", init="random", tol=3e-3, mask=False, defer=False, iters=30), 29612)
 
 
-def test_gloo_adam():
+def test_gloo_adam_fused():
     _check(dict(method="adam", init="baseline", tol=None, mask=True, defer=True, iters=4), 29613)
+
+
+def test_gloo_adam_autograd():
+    _check(dict(method="adam", init="baseline", tol=1e-12, mask=False, defer=True, iters=4, fused=False), 29614)

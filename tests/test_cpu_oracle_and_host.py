@@ -114,14 +114,14 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libdfx.so does not export {n}"
-    assert cabi.lib().dfx_version() == 101
+    assert cabi.lib().dfx_version() == 102
 
 
 def test_header_constants_match_python_mirror():
     from datafusion_amd import _cabi as cabi
     src = open(os.path.join(ROOT, "include", "dfx.h")).read()
     for name in ("RSOLD", "RSNEW", "PAP", "ALPHA", "BETA", "TOL", "UU", "PP", "XX", "XP", "VV", "RR", "XXNEW",
-                 "NONFINITE", "ITER", "SUM", "SCALE", "LOSS1", "LOSS2"):
+                 "NONFINITE", "ITER", "SUM", "SCALE", "LOSS1", "LOSS2", "ADAM_DD", "ADAM_XX"):
         m = re.search(rf"DFX_S_{name}\s*=\s*(\d+)", src)
         assert m and int(m.group(1)) == getattr(cabi, "S_" + name), name
     assert int(re.search(r"DFX_NSCAL\s*=\s*(\d+)", src).group(1)) == cabi.NSCAL
@@ -227,11 +227,13 @@ def test_host_logic_zeros_diverges_and_verbose_history(golden, cpu_backend):
     assert np.allclose(f.history[:, :3], g["hist"][:5, :3], rtol=2e-3, atol=1e-12)
 
 
-def test_host_logic_adam(golden, cpu_backend):
+@pytest.mark.parametrize("fused", [True, False])
+def test_host_logic_adam(golden, cpu_backend, fused):
     from datafusion_amd import FusionAdam
     for name, mask, nn in (("adam_t6l4z3_32", False, False), ("adam_t6l4z3_32_mask_nn", True, True)):
         g = golden(name)
-        f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu", mask_noise=mask)
+        f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu", mask_noise=mask,
+                       fused=fused)
         l1, l2 = f.loss()
         assert np.allclose([float(l1), float(l2)], g["loss0"], rtol=1e-3)
         x, _, _ = f(lr=float(g["lr"]), max_iterations=5, non_neg=nn)

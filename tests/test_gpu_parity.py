@@ -93,11 +93,13 @@ def test_baseline_function(golden):
     assert np.max(np.abs(x - g["x"])) <= 1e-6 * np.max(np.abs(g["x"])) * 4
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name,mask,nn", [("adam_t6l4z3_32", False, False), ("adam_t6l4z3_32_mask_nn", True, True)])
-def test_adam_matches_reference(golden, name, mask, nn):
+def test_adam_matches_reference(golden, name, mask, nn, fused):
     from datafusion_amd import FusionAdam
     g = golden(name)
-    f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, mask_noise=mask)
+    f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, mask_noise=mask,
+                   fused=fused)
     assert O.rel_l2(f.x.cpu(), g["x0"]) <= TIGHT
     l1, l2 = f.loss()
     assert np.allclose([float(l1), float(l2)], g["loss0"], rtol=1e-3)
@@ -170,3 +172,24 @@ def test_collapsed_oracle_agrees_with_gpu_at_mid_size():
     a, g, _, _ = O.collapsed_cg(f.spc.cpu(), f.cmos.cpu(), u0, v0, f.x_shape, 4, 0.5, 0.5, 10)
     xc = O.expand_small(x0.cpu(), a, g, 4)
     assert O.rel_l2(x.cpu(), xc) <= TIGHT
+
+
+@pytest.mark.parametrize("shape,mask,nn,tol", [((6, 4, 8, 64, 4), False, False, None), ((5, 3, 11, 128, 4), True, True, None),
+                                               ((6, 4, 5, 64, 4), False, True, 1e-3)])
+def test_adam_fused_fast_path_vs_oracle(shape, mask, nn, tol):
+    """Fused dfx_adam_step (fast kernels) vs torch.optim.Adam on the CPU oracle, cells-like data."""
+    from datafusion_amd import FusionAdam
+    w = {"spatial": 0.5, "spectro_temporal": 0.5}
+    spc, cmos = O.cells_like_inputs(*shape, seed=12)
+    lr = 1e-7
+    f = FusionAdam(spc, cmos, weights=w, init_type="baseline", tol=tol, device=DEV, mask_noise=mask)
+    assert f.k.plan.fast == 1
+    x, _, _ = f(lr=lr, max_iterations=8, non_neg=nn)
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=tol, mask_noise=mask)
+    xo = O.adam(pb, lr, 8, non_neg=nn)
+    assert f.curr_iter == pb.curr_iter
+    assert O.rel_l2(x, xo) <= TIGHT
+    # the autograd formulation over the same kernels gives the same iterate
+    f2 = FusionAdam(spc, cmos, weights=w, init_type="baseline", tol=tol, device=DEV, mask_noise=mask, fused=False)
+    x2, _, _ = f2(lr=lr, max_iterations=8, non_neg=nn)
+    assert O.rel_l2(x2, x) <= TIGHT
