@@ -64,12 +64,52 @@ def cpu_baseline(n_l, n_z, xy, r, full_n, budget_s=20.0):
                       f"in {dt:.1f}s incl. b/r0 every 2 iterations = {its:.3f} it/s, scaled by N_sample/N_full"}
 
 
+def bench_adam(a, world, rank, dev, group):
+    """Secondary metric (BASELINE.json configs[4]): FusionAdam iterations/s, lr = 1e-8 as analysis/runtime.py:95."""
+    from datafusion_amd import FusionAdam
+    n_t, n_l, nz_gpu, xy, r = WORKLOADS[a.workload]
+    spc, cmos = synthetic(n_t, n_l, nz_gpu * world, xy, r)
+    f = FusionAdam(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
+                   device=dev, group=group, fused=(a.method == "adam"))
+    n_local = f.k.N
+    f(lr=1e-8, max_iterations=a.warmup, return_numpy=False)
+    f.k.timing = {}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    f(lr=1e-8, max_iterations=a.steps, return_numpy=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs) for name, evs in f.k.timing.items()}
+    its = a.steps / dt
+    out = {"metric": "FusionAdam iters/sec (secondary; BASELINE.json configs[4] shape class)", "value": its, "unit": "it/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"FusionAdam ({a.method}) t{n_t} x l{n_l} x z{nz_gpu * world} x {xy} x {xy}, r={r}, lr=1e-8",
+                      "n_elements": n_local * world}, "kernel_ms": kern}
+    if a.method == "adam":
+        ach = 24.0 * n_local / (kern["adam"] * 1e-3) / 1e9      # x, m1, m2 read + written
+        out["roofline"] = {"bound": "hbm", "kernel": f"k_adam_fast<{f.k.plan.zc}>", "achieved": ach,
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                           "bytes_per_launch": 24 * n_local, "avg_launch_ms": kern["adam"]}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--method", default="cg", choices=["cg", "adam", "adam-autograd"],
+                    help="cg (the headline metric) | adam: fused dfx_adam_step | adam-autograd: autograd.Function + torch Adam")
     ap.add_argument("--no-defer", action="store_true", help="textbook ordering (x updated with r): 8N words/iter")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--target-blocks", type=int, default=0)
@@ -89,6 +129,8 @@ def main():
         group = dist.group.WORLD
 
     from datafusion_amd import FusionCG
+    if a.method != "cg":
+        return bench_adam(a, world, rank, dev, group)
     n_t, n_l, nz_gpu, xy, r = WORKLOADS[a.workload]
     n_z = nz_gpu * world
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
