@@ -174,7 +174,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if pmc["workload"] == a.workload and world == 1 and not a.no_defer:
-            traffic = pmc["k_sweep_fast<1,8>"]["traffic_bytes"]
+            traffic = pmc["kernels"][f"k_sweep_fast<1, {f.k.plan.zc}>"]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     out = {

@@ -1,0 +1,32 @@
+# rocprofv3 kernel-trace stats + the two PMC passes for the default bench (C2).  Usage: bash tools/profile_all.sh <tag>
+set -e
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --no-cpu --steps 20 > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_$TAG.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$c -- python3 bench.py --no-cpu --steps 4 --warmup 1 > gpurun_out/pmc_${TAG}_$c.json 2> gpurun_out/pmc_${TAG}_$c.err
+done
+python3 - $TAG <<'PY'
+import csv, glob, collections, sys, json
+tag = sys.argv[1]
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"gpurun_out/pmc_{tag}_{c}/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f[0])):
+        if row["Counter_Name"] == c:
+            agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    for k, v in agg.items():
+        if max(v) > 100000:
+            short = k.split("(anonymous namespace)::")[1].split("(")[0] if "(anonymous namespace)::" in k else k[:50]
+            print(c, short, "n=%d" % len(v), "avg_KiB=%.1f" % (sum(v) / len(v)))
+            res.setdefault(short, {})[c] = sum(v) / len(v)
+out = {}
+for k, d in res.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        out[k] = {"FETCH_SIZE_KiB": d["FETCH_SIZE"], "WRITE_SIZE_KiB": d["WRITE_SIZE"],
+                  "traffic_bytes": int(d["FETCH_SIZE"] * 2 * 1024 + d["WRITE_SIZE"] * 1024)}
+json.dump(out, open(f"gpurun_out/pmc_{tag}_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/prof_${TAG}_kernel_stats.csv; head -8 $f | cut -c1-150
