@@ -64,7 +64,7 @@ def cpu_baseline(n_l, n_z, xy, r, full_n, budget_s=20.0):
                       f"in {dt:.1f}s incl. b/r0 every 2 iterations = {its:.3f} it/s, scaled by N_sample/N_full"}
 
 
-def bench_adam(a, world, rank, dev, group):
+def bench_adam(a, world, rank, dev, group, use_dist):
     """Secondary metric (BASELINE.json configs[4]): FusionAdam iterations/s, lr = 1e-8 as analysis/runtime.py:95."""
     from datafusion_amd import FusionAdam
     n_t, n_l, nz_gpu, xy, r = WORKLOADS[a.workload]
@@ -75,12 +75,12 @@ def bench_adam(a, world, rank, dev, group):
     f(lr=1e-8, max_iterations=a.warmup, return_numpy=False)
     f.k.timing = {}
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     f(lr=1e-8, max_iterations=a.steps, return_numpy=False)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs) for name, evs in f.k.timing.items()}
@@ -97,7 +97,7 @@ def bench_adam(a, world, rank, dev, group):
                            "bytes_per_launch": 24 * n_local, "avg_launch_ms": kern["adam"]}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -123,14 +123,16 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     group = None
-    if world > 1:
+    # DFX_FORCE_COMM=1 under torch.distributed.run: take the RCCL code path even with one rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or (os.environ.get("DFX_FORCE_COMM") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
         group = dist.group.WORLD
 
     from datafusion_amd import FusionCG
     if a.method != "cg":
-        return bench_adam(a, world, rank, dev, group)
+        return bench_adam(a, world, rank, dev, group, use_dist)
     n_t, n_l, nz_gpu, xy, r = WORKLOADS[a.workload]
     n_z = nz_gpu * world
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
@@ -142,7 +144,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -156,7 +158,7 @@ def main():
     dt = time.perf_counter() - t0
     timing, f.k.timing = f.k.timing, None
     f.finish()  # raises if the residual ever went non-finite
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -199,7 +201,7 @@ def main():
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_l, n_z, xy, r, n_total)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -746,6 +746,31 @@ __global__ __launch_bounds__(256) void k_scale(float *y, long long n, const floa
     }
 }
 
+// out[a][b] = sum_{k < R} x[(a*R + k)*B + b]: the marginals a caller takes right after a solve
+// (x.sum(axis=0) -> A=1,R=nT ; x.sum(axis=1) -> A=nT,R=nL ; cells.ipynb cell 27bf9830e81df430), one read of x.
+__global__ __launch_bounds__(256) void k_sum_axis(const float *x, float *out, long long A, long long R, long long B) {
+    const long long B4 = ((B & 3) == 0 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0)) ? (B >> 2) : 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (B4) {
+        for (long long j = t0; j < A * B4; j += stride) {
+            const long long a = j / B4, b = (j - a * B4) * 4;
+            const float *src = x + a * R * B + b;
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (long long k = 0; k < R; ++k) acc += ld4s(src + k * B);
+            st4(out + a * B + b, acc);
+        }
+    } else {
+        for (long long j = t0; j < A * B; j += stride) {
+            const long long a = j / B, b = j - a * B;
+            const float *src = x + a * R * B + b;
+            float acc = 0.f;
+            for (long long k = 0; k < R; ++k) acc += src[k * B];
+            out[a * B + b] = acc;
+        }
+    }
+}
+
 struct BaseArgs {
     const float *spc;
     const float *zw;
@@ -1182,6 +1207,17 @@ int dfx_scale(float *y, int64_t n, const float *mask, int64_t mask_n, float coef
     hipLaunchKernelGGL(k_scale, dim3(ew_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, y, (long long)n, mask,
                        (long long)(mask ? mask_n : 1), coef_host, coef_dev);
     DFX_LAUNCH_CHECK("dfx_scale");
+    return 0;
+}
+
+int dfx_sum_axis(const float *x, float *out, int64_t A, int64_t R, int64_t B, void *stream) {
+    if (!x || !out || A <= 0 || R <= 0 || B <= 0) return fail(DFX_EINVAL, "dfx_sum_axis: bad argument");
+    const long long items = (long long)A * ((B & 3) == 0 ? B / 4 : B);
+    long long nb = (items + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(k_sum_axis, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, out, (long long)A,
+                       (long long)R, (long long)B);
+    DFX_LAUNCH_CHECK("dfx_sum_axis");
     return 0;
 }
 

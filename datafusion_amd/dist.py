@@ -5,6 +5,8 @@ exchanges per CG iteration are the sum of the spc-sized RD partial v and a handf
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -24,6 +26,7 @@ class ShardComm:
     def __init__(self, group=None):
         if group is None or not dist.is_initialized():
             self.group, self.size, self.rank = None, 1, 0
+            self._stage = False
         else:
             self.group = group if group is not True else dist.group.WORLD
             self.size = dist.get_world_size(self.group)
@@ -31,9 +34,12 @@ class ShardComm:
             # a gloo group cannot reduce device memory: stage through the host (debug / test set-ups where
             # several ranks share one GPU; production groups are "nccl" = RCCL and reduce in place)
             self._stage = dist.get_backend(self.group) == "gloo"
+        # DFX_FORCE_COMM=1: issue the collectives even on a one-rank group (a sum over one rank is the identity);
+        # lets a single-GPU box exercise the real RCCL call path
+        self._always = self.group is not None and os.environ.get("DFX_FORCE_COMM") == "1"
 
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.size > 1:
+        if self.size > 1 or self._always:
             if self._stage and t.device.type != "cpu":
                 h = t.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)

@@ -204,6 +204,21 @@ class Fusion:
         self._project(x)
         return self._losses_from_uv()
 
+    def marginals(self, which: str = "tl") -> torch.Tensor:
+        """Device-side reductions of the fused volume (what the notebooks compute with numpy after a
+        4-128 GiB device-to-host copy, cells.ipynb cell 27bf9830e81df430), on this rank's z planes:
+          "tl" -> x.sum(axis=(0, 1))  (z, x, y)   [= u(x)]
+          "t"  -> x.sum(axis=0)       (l, z, x, y)
+          "l"  -> x.sum(axis=1)       (t, z, x, y)
+          "zxy"-> R(D(x))             (t, l, x/r, y/r), summed over shards  [= v(x)]"""
+        x = self.x.detach()
+        if which in ("tl", "zxy"):
+            self._project(x)
+            return (self.k.u if which == "tl" else self.k.v).clone()
+        if which in ("t", "l"):
+            return self.k.sum_axis(x, 0 if which == "t" else 1)
+        raise ValueError("which must be one of 'tl', 't', 'l', 'zxy'")
+
     def tolerance(self) -> torch.Tensor:
         """fusion.py:244-252: ||x - prev_x|| / ||x|| of the last completed iteration (device scalar)."""
         return self.k.scal[cabi.S_TOL].float()

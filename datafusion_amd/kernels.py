@@ -141,6 +141,20 @@ class HipKernels:
         cabi.check(self.lib.dfx_sum(cabi.ptr(y), y.numel(), cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()),
                    "dfx_sum")
 
+    def sum_axis(self, x, axis: int):
+        """x.sum(axis) for axis 0 (time) or 1 (lambda) of the local (t, l, z, x, y) shard -> new tensor."""
+        self._chk(x)
+        n_t, n_l = self.shape[0], self.shape[1]
+        if axis == 0:
+            A, R, B, shape = 1, n_t, n_l * self.S, self.shape[1:]
+        elif axis == 1:
+            A, R, B, shape = n_t, n_l, self.S, (n_t,) + tuple(self.shape[2:])
+        else:
+            raise ValueError("sum_axis: axis must be 0 (time) or 1 (lambda); (0, 1) is project()")
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        cabi.check(self.lib.dfx_sum_axis(cabi.ptr(x), cabi.ptr(out), A, R, B, self._stream()), "dfx_sum_axis")
+        return out
+
     def recip(self, dst_slot: int, src_slot: int, num: float) -> None:
         cabi.check(self.lib.dfx_recip(self.slot_ptr(dst_slot), self.slot_ptr(src_slot), num, self._stream()),
                    "dfx_recip")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 102
+#define DFX_VERSION 103
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -153,6 +153,10 @@ int dfx_scale(float *y, int64_t n, const float *mask, int64_t mask_n, float coef
               const double *coef_dev, void *stream);
 /* scal[DFX_S_SUM] = sum_i y[i]  (fusion.py:209 tensor.sum()). */
 int dfx_sum(const float *y, int64_t n, double *scal, double *part, void *stream);
+/* out[a][b] = sum_{k<R} x[(a*R + k)*B + b]  (x viewed as (A, R, B)): the marginals callers take right after a
+ * solve - x.sum(axis=0): A=1, R=nT; x.sum(axis=1): A=nT, R=nL (analysis/cells.ipynb cell 27bf9830e81df430) -
+ * computed on the device so the 5-D volume need not cross PCIe (fusion.py:489-493 returns it whole). */
+int dfx_sum_axis(const float *x, float *out, int64_t A, int64_t R, int64_t B, void *stream);
 /* dst[0] = num / src[0]  (device scalars; total_energy / sum, fusion.py:209). */
 int dfx_recip(double *dst, const double *src, double num, void *stream);
 

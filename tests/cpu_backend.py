@@ -70,6 +70,9 @@ class CpuStandIn:
         self.scal[cabi.S_ADAM_DD] = ((x - x_old).double() ** 2).sum()
         self.scal[cabi.S_ADAM_XX] = (x.double() ** 2).sum()
 
+    def sum_axis(self, x, axis):
+        return x.sum(axis)
+
     def sqnorm_v(self):
         self.scal[cabi.S_VV] = (self.v.double() ** 2).sum()
 

@@ -109,12 +109,12 @@ def _declared_functions():
 def test_library_exports_every_declared_symbol():
     from datafusion_amd import _cabi as cabi
     names = _declared_functions()
-    assert len(names) >= 17
+    assert len(names) >= 20
     assert sorted(cabi.SIGNATURES) == names, "ctypes table and include/dfx.h disagree"
     lib = C.CDLL(cabi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libdfx.so does not export {n}"
-    assert cabi.lib().dfx_version() == 102
+    assert cabi.lib().dfx_version() == 103
 
 
 def test_header_constants_match_python_mirror():

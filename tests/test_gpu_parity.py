@@ -193,3 +193,18 @@ def test_adam_fused_fast_path_vs_oracle(shape, mask, nn, tol):
     f2 = FusionAdam(spc, cmos, weights=w, init_type="baseline", tol=tol, device=DEV, mask_noise=mask, fused=False)
     x2, _, _ = f2(lr=lr, max_iterations=8, non_neg=nn)
     assert O.rel_l2(x2, x) <= TIGHT
+
+
+@pytest.mark.parametrize("shape", [(6, 4, 8, 64, 4), (5, 3, 3, 24, 4)])
+def test_marginals_on_device(shape):
+    from datafusion_amd import FusionCG
+    spc, cmos = O.synthetic_inputs(*shape, seed=13)
+    f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None, device=DEV)
+    x, _, _ = f(3)
+    xd = torch.from_numpy(x).double()
+    r = f.spatial_increase
+    assert O.rel_l2(f.marginals("tl").cpu(), xd.sum((0, 1))) <= 1e-6
+    assert O.rel_l2(f.marginals("t").cpu(), xd.sum(0)) <= 1e-6
+    assert O.rel_l2(f.marginals("l").cpu(), xd.sum(1)) <= 1e-6
+    v = xd.sum(2).reshape(shape[0], shape[1], shape[3] // r, r, shape[3] // r, r).sum((3, 5))
+    assert O.rel_l2(f.marginals("zxy").cpu(), v) <= 1e-6

@@ -108,3 +108,37 @@ def test_z_sharded_hip_path_three_ranks_on_one_gpu():
     assert O.rel_l2(full, O.cg(pb, 10, with_loss=False)) <= 2e-5
     m1, m2 = f.loss()
     assert np.allclose([l1, l2], [float(m1), float(m2)], rtol=1e-3, atol=1e-16)
+
+
+def _rccl_worker(port, q):
+    sys.path[:0] = [ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DFX_FORCE_COMM="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    from datafusion_amd import FusionAdam, FusionCG
+    from oracle import fusion_oracle as Or
+    spc, cmos = Or.synthetic_inputs(6, 4, 8, 64, 4, seed=6)
+    f = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=3e-3, device=DEV, group=dist.group.WORLD)
+    assert f.comm._always and f.comm.group is not None
+    x, _, _ = f(10)
+    g = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, group=dist.group.WORLD)
+    xa, _, _ = g(lr=1e-7, max_iterations=3)
+    q.put((x, f.curr_iter, xa))
+    dist.destroy_process_group()
+
+
+def test_collectives_through_real_rccl_one_rank():
+    """Every all-reduce of the sharded path issued through backend nccl (= RCCL) on a one-rank group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29641, q))
+    p.start()
+    x, it, xa = q.get(timeout=150)
+    p.join(60)
+    assert p.exitcode == 0
+    spc, cmos = O.synthetic_inputs(6, 4, 8, 64, 4, seed=6)
+    pb = O.prepare(spc, cmos, weights=W, init_type="baseline", tol=3e-3)
+    xo = O.cg(pb, 10, with_loss=False)
+    assert it == pb.curr_iter and O.rel_l2(x, xo) <= 2e-5
+    pb = O.prepare(spc, cmos, weights=W, init_type="baseline", tol=None)
+    assert O.rel_l2(xa, O.adam(pb, 1e-7, 3)) <= 2e-5
