@@ -83,7 +83,7 @@ def bench_adam(a, world, rank, dev, group, use_dist):
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs) for name, evs in f.k.timing.items()}
+    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in f.k.timing.items()}
     its = a.steps / dt
     out = {"metric": "FusionAdam iters/sec (secondary; BASELINE.json configs[4] shape class)", "value": its, "unit": "it/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -96,13 +96,26 @@ def bench_adam(a, world, rank, dev, group, use_dist):
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                            "bytes_per_launch": 24 * n_local, "avg_launch_ms": kern["adam"]}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def emit(obj):
+    """The ONE JSON line goes to the process's original stdout; everything else any library prints on fd 1
+    (RCCL prints a version banner there at communicator creation) was diverted to stderr in main()."""
+    os.write(_REAL_STDOUT, (json.dumps(obj) + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def main():
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -164,7 +177,8 @@ def main():
         dt = float(t)
 
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
-    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs) for name, evs in timing.items()}
+    # per-iteration time of each entry point (a z-sharded sweep is cut into several launches: sum them)
+    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in timing.items()}
     sweep_name = "sweep2" if a.no_defer else "sweep1"
     sweep_ms = kern[sweep_name]
     sweep_bytes = (3 if a.no_defer else 5) * 4 * n_local          # words the kernel must move
@@ -187,6 +201,7 @@ def main():
         "config": {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r}, tol=None, baseline init "
                                f"({a.workload}; {nz_gpu} z-planes per GPU)", "n_elements": n_total,
                    "parallelism": f"z-shard x{world}", "x_update": "textbook" if a.no_defer else "deferred",
+                   "sweep_launches_per_iteration": len(timing[sweep_name]) // a.steps,
                    "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "cpb", "n_blocks")}},
         # whole iteration, all GPUs: SURVEY 8(d) prices an iteration at 32 N bytes; this build moves 28 N
         "hbm_effective_GBps": 32.0 * n_total * its / 1e9,
@@ -200,7 +215,7 @@ def main():
     if rank == 0:
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_l, n_z, xy, r, n_total)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -30,6 +30,7 @@ S_RSOLD, S_RSNEW, S_PAP, S_ALPHA, S_BETA, S_TOL, S_UU, S_PP, S_XX, S_XP, S_VV, S
 NSCAL = 32
 NPART = 4
 EW_MAXBLOCKS = 2048
+MAX_SLICES = 16
 SWEEP_PROJECT, SWEEP_XP, SWEEP_P, SWEEP_PINIT = range(4)
 
 _P = C.c_void_p
@@ -47,7 +48,8 @@ SIGNATURES = {
     "dfx_bcast": [_G, _PL, _P, _P, _P, _P, _P, _f, _f, _f, _P, _P, _P, _P],
     "dfx_adam_step": [_G, _PL, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _i32, _i32, _P, _P, _P, _P, _P],
     "dfx_reduce_u": [_G, _PL, _P, _P, _P, _P, _P],
-    "dfx_reduce_v": [_G, _PL, _P, _P, _P],
+    "dfx_reduce_v": [_G, _PL, _P, _P, _i64, _i64, _P],
+    "dfx_sweep_chunks": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P],
     "dfx_sqnorm": [_P, _i64, _P, _i32, _P, _P],
     "dfx_sqdiff": [_P, _P, _P, _i64, _i64, _d, _P, _i32, _P, _P],
     "dfx_cg_alpha": [_P, _d, _d, _d, _P],

@@ -30,9 +30,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef DFX_WAVES
 #define DFX_WAVES 4       // waves per workgroup of the fast kernels (each wave owns one wave tile)
 #endif
-#ifndef DFX_INTERLEAVE
-#define DFX_INTERLEAVE 1  // 1: concurrently running workgroups take ADJACENT slabs (m = i*gz + z): one contiguous
-#endif                    //    moving window in HBM; 0: each workgroup owns a contiguous run of slabs
 #ifndef DFX_BCAST_INFLIGHT
 #define DFX_BCAST_INFLIGHT 8  // float4 loads a lane of k_bcast_fast keeps in flight (slabs per trip = this / zc)
 #endif
@@ -162,7 +159,9 @@ struct SweepArgs {
     Geo q;
     int steps;     // slabs per u_part chunk (flush interval of the u accumulators)
     int n_chunks;  // ceil(M / steps)
-    int cpb;       // consecutive chunks one workgroup walks through
+    int cpb;       // chunks one workgroup walks through in a full sweep
+    int c_lo, c_hi;  // chunk range of THIS launch (a full sweep is [0, cpb))
+    int row0;      // first row of `part` this launch writes
 };
 
 template <int MODE, int ZC, bool FULL>
@@ -257,17 +256,14 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
             (long long)blockIdx.y * a.q.M * a.q.Ps + (long long)tx * a.q.Ys + ty * 16 + (lane & 15);
         const float fa = (MODE == DFX_SWEEP_XP) ? (float)a.scal[DFX_S_ALPHA] : 0.f;
         const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)a.scal[DFX_S_BETA] : 0.f;
-        for (int c = 0; c < a.cpb; ++c) {
+        for (int c = a.c_lo; c < a.c_hi; ++c) {
             // the u accumulators are flushed every `steps` slabs: bounds the length of an fp32 running sum
-#if DFX_INTERLEAVE
+            // concurrently running workgroups take ADJACENT slabs (m = i*gz + bz): the chip streams one
+            // contiguous moving window of each vector; chunk c of every workgroup covers slabs
+            // [c*steps*gz, (c+1)*steps*gz), so a range of chunks is a contiguous range of slabs
             const int m0 = c * a.steps * gz + bz, ms = gz;
             const int m1 = min((c + 1) * a.steps * gz, a.q.M);
             const int chunk = c * gz + bz;
-#else
-            const int m0 = (bz * a.cpb + c) * a.steps, ms = 1;
-            const int m1 = min(m0 + a.steps, a.q.M);
-            const int chunk = bz * a.cpb + c;
-#endif
             f4 uacc[ZC];
 #pragma unroll
             for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -282,7 +278,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
         }
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    block_store3(dpp, dxx, dxp, a.part + bid * DFX_NPART);
+    block_store3(dpp, dxx, dxp, a.part + (a.row0 + bid) * DFX_NPART);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -351,12 +347,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(con
     const int wt = blockIdx.x * DFX_WAVES + wave;
     const int z0 = blockIdx.y * ZC;
     const int zcnt = min(ZC, a.q.nZ - z0);
-#if DFX_INTERLEAVE
     const int m0 = blockIdx.z, ms = gridDim.z, m1 = a.q.M;
-#else
-    const int m0 = blockIdx.z * a.cpb * a.steps, ms = 1;
-    const int m1 = min(m0 + a.cpb * a.steps, a.q.M);
-#endif
     double drr = 0;
     if (wt < a.q.WT) {
         const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
@@ -630,9 +621,10 @@ __global__ __launch_bounds__(256) void k_reduce_u(const float *u_part, float *u,
     block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
 }
 
-__global__ __launch_bounds__(256) void k_reduce_v(const float *v_part, float *v, long long len, int n_zchunks) {
+__global__ __launch_bounds__(256) void k_reduce_v(const float *v_part, float *v, long long lo, long long hi,
+                                                  long long len, int n_zchunks) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
         float s = 0.f;
         for (int c = 0; c < n_zchunks; ++c) s += v_part[(long long)c * len + i];
         v[i] = s;
@@ -981,16 +973,28 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
     }
     out->u_part_elems = (long long)out->n_chunks * q.S;
     out->v_part_elems = (long long)out->n_zchunks * q.M * q.Ps;
-    const long long rows = out->n_blocks > DFX_EW_MAXBLOCKS ? out->n_blocks : DFX_EW_MAXBLOCKS;
+    long long rows = (long long)out->n_blocks * DFX_MAX_SLICES;
+    if (rows < DFX_EW_MAXBLOCKS) rows = DFX_EW_MAXBLOCKS;
     out->part_elems = rows * DFX_NPART;
     return 0;
 }
 
 int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
               double *scal, float *u_part, float *v_part, double *part, void *stream) {
+    if (!pl) return fail(DFX_EPLAN, "plan is NULL");
+    return dfx_sweep_chunks(mode, g, pl, x, r, p, scal, u_part, v_part, part, 0, pl->cpb, 0, 1, stream);
+}
+
+int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
+                     double *scal, float *u_part, float *v_part, double *part, int32_t c_lo, int32_t c_hi,
+                     int32_t slice, int32_t last, void *stream) {
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
+    if (c_lo < 0 || c_hi > pl->cpb || c_lo >= c_hi || slice < 0 || slice >= DFX_MAX_SLICES)
+        return fail(DFX_EINVAL, "dfx_sweep_chunks: need 0 <= c_lo < c_hi <= cpb and 0 <= slice < DFX_MAX_SLICES");
+    if (!pl->fast && (c_lo != 0 || c_hi != pl->cpb || slice != 0 || !last))
+        return fail(DFX_EINVAL, "dfx_sweep_chunks: the generic path sweeps whole volumes only");
     if (mode < DFX_SWEEP_PROJECT || mode > DFX_SWEEP_PINIT) return fail(DFX_EINVAL, "dfx_sweep: bad mode");
     if (!x || !scal || !u_part || !v_part || !part) return fail(DFX_EINVAL, "dfx_sweep: NULL buffer");
     if (mode != DFX_SWEEP_PROJECT && (!r || !p)) return fail(DFX_EINVAL, "dfx_sweep: r and p required");
@@ -999,7 +1003,8 @@ int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, con
     if (pl->fast) {
         if (!aligned16(x) || !aligned16(r) || !aligned16(p) || !aligned16(u_part))
             return fail(DFX_EALIGN, "dfx_sweep: x, r, p, u_part must be 16-byte aligned");
-        SweepArgs a{x, r, p, scal, u_part, v_part, part, q, pl->steps, pl->n_chunks, pl->cpb};
+        SweepArgs a{x, r, p, scal, u_part, v_part, part, q, pl->steps, pl->n_chunks, pl->cpb, c_lo, c_hi,
+                    slice * pl->n_blocks};
         int rc;
         switch (mode) {
             case DFX_SWEEP_PROJECT: rc = launch_sweep_fast<DFX_SWEEP_PROJECT>(a, pl, st); break;
@@ -1008,7 +1013,7 @@ int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, con
             default: rc = launch_sweep_fast<DFX_SWEEP_PINIT>(a, pl, st); break;
         }
         if (rc) return rc;
-        n_rows = pl->n_blocks;
+        n_rows = (slice + 1) * pl->n_blocks;
     } else {
         const int nb = pl->n_blocks;
         switch (mode) {
@@ -1033,7 +1038,8 @@ int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, con
         DFX_LAUNCH_CHECK("dfx_sweep(generic v)");
         n_rows = nb;
     }
-    // (pp, xx, xp) -> scal[PP], scal[XX], scal[XP] (consecutive slots)
+    // (pp, xx, xp) -> scal[PP], scal[XX], scal[XP] (consecutive slots), over the rows of every slice so far
+    if (!last) return 0;
     return fold(part, n_rows, 3, scal + DFX_S_PP, 1.0, st);
 }
 
@@ -1126,14 +1132,16 @@ int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, flo
     return fold(part, nb, 1, scal + DFX_S_UU, 1.0, st);
 }
 
-int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, float *v, void *stream) {
+int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, float *v, int64_t m_lo, int64_t m_hi,
+                 void *stream) {
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
     if (!v_part || !v) return fail(DFX_EINVAL, "dfx_reduce_v: NULL buffer");
+    if (m_lo < 0 || m_hi > q.M || m_lo >= m_hi) return fail(DFX_EINVAL, "dfx_reduce_v: bad slab range");
     const long long len = (long long)q.M * q.Ps;
-    hipLaunchKernelGGL(k_reduce_v, dim3(ew_blocks(len, 1)), dim3(256), 0, (hipStream_t)stream, v_part, v, len,
-                       pl->n_zchunks);
+    hipLaunchKernelGGL(k_reduce_v, dim3(ew_blocks((m_hi - m_lo) * q.Ps, 1)), dim3(256), 0, (hipStream_t)stream, v_part,
+                       v, (long long)m_lo * q.Ps, (long long)m_hi * q.Ps, len, pl->n_zchunks);
     DFX_LAUNCH_CHECK("dfx_reduce_v");
     return 0;
 }

@@ -38,6 +38,23 @@ class ShardComm:
         # lets a single-GPU box exercise the real RCCL call path
         self._always = self.group is not None and os.environ.get("DFX_FORCE_COMM") == "1"
 
+    def sum_async(self, t: torch.Tensor):
+        """Start a sum-all-reduce of `t` ordered after the work already queued on the current stream; returns a
+        handle for wait() (None when nothing is pending: one shard, or a host-staged gloo group)."""
+        if not (self.size > 1 or self._always):
+            return None
+        if self._stage and t.device.type != "cpu":
+            self.sum_(t)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @staticmethod
+    def wait(handles) -> None:
+        """Make the current stream wait for the collectives started by sum_async (no host block with RCCL)."""
+        for h in handles:
+            if h is not None:
+                h.wait()
+
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.size > 1 or self._always:
             if self._stage and t.device.type != "cpu":

@@ -236,18 +236,31 @@ class Fusion:
 class FusionCG(Fusion):
     """Conjugate gradient on the normal equations (fusion.py:389-496)."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, comm_slices: int = 4, **kwargs):
         super().__init__(*args, **kwargs)
         self.w1 = self.weights["spatial"]
         self.w2 = self.weights["spectro_temporal"]
         self._r = self._p = None
+        self.comm_slices = int(comm_slices)
         self._pending_x = False
         self._stopped = False
 
-    def _finish_projection(self) -> None:
-        """After a sweep that produced u(p), v(p) partials: cross-shard sums + ||v||^2."""
+    def _sweep(self, mode) -> None:
+        """One pass over x, r, p.  When the volume is z-sharded the pass is cut into `comm_slices` launches along
+        the slab axis and the all-reduce of each finished band of v (the RD partials, the one real exchange,
+        SURVEY 8e) is started on RCCL's stream while the next band is still being swept."""
         k, c = self.k, self.comm
-        c.sum_(k.v)                                   # RD partials: the one real exchange (SURVEY 8e)
+        if c.size > 1 or c._always:
+            pending = []
+            k.sweep(mode, self.x, self._r, self._p, slices=self.comm_slices,
+                    after_slice=lambda rows: pending.append(c.sum_async(rows)))
+            c.wait(pending)
+        else:
+            k.sweep(mode, self.x, self._r, self._p)
+
+    def _finish_projection(self) -> None:
+        """After _sweep (v already summed over shards): ||v||^2 and the scalar partials."""
+        k, c = self.k, self.comm
         k.sqnorm_v()                                  # VV identical on every rank
         c.sum_(k.scal[cabi.S_UU:cabi.S_XP + 1])       # UU, PP, XX, XP partials
 
@@ -272,7 +285,7 @@ class FusionCG(Fusion):
         k.bcast(rv, None, du, dv, None, c1, c2, 1.0, None)
         c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
         k.cg_start()                                                            # rsold (fusion.py:437)
-        k.sweep(cabi.SWEEP_PINIT, x, rv, pv)                                    # p = r (fusion.py:436)
+        self._sweep(cabi.SWEEP_PINIT)                                           # p = r (fusion.py:436)
         self._finish_projection()
         self._pending_x = False
         self._stopped = False
@@ -307,7 +320,7 @@ class FusionCG(Fusion):
             if history is not None:                                             # fusion.py:458-478
                 l1, l2 = self.loss()                                            # x is current: defer_x is off
                 history[i] = [float(l1), float(l2), float(l1) + float(l2), float(s[cabi.S_RSNEW])]
-            k.sweep(cabi.SWEEP_XP if deferred else cabi.SWEEP_P, x, rv, pv)     # fusion.py:445,455
+            self._sweep(cabi.SWEEP_XP if deferred else cabi.SWEEP_P)            # fusion.py:445,455
             self._pending_x = False
             self._finish_projection()
 

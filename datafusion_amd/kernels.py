@@ -72,20 +72,36 @@ class HipKernels:
                 assert t.device == self.scal.device and t.dtype == torch.float32 and t.is_contiguous()
 
     # -- 5-D passes -----------------------------------------------------------------------
-    def sweep(self, mode: int, x, r=None, p=None) -> None:
-        """u(.) -> self.u (+UU), local v partial -> self.v, PP/XX/XP -> scal."""
+    def sweep(self, mode: int, x, r=None, p=None, slices: int = 1, after_slice=None) -> None:
+        """u(.) -> self.u (+UU), local v partial -> self.v, PP/XX/XP -> scal.
+        slices > 1 cuts the pass along the slab axis into that many launches (fast plans; at most cpb);
+        after_slice(v_rows) is called after each one with the rows of self.v (viewed (nT*nL, Xs*Ys)) that
+        are final - the hook the z-sharded solver uses to start their all-reduce while the sweep goes on."""
         self._chk(x, r, p)
         for t in (x, r, p):
             assert t is None or t.numel() == self.N
         g, pl = self._g()
         s = self._stream()
-        cabi.check(self._timed(f"sweep{mode}", self.lib.dfx_sweep, mode, g, pl, cabi.ptr(x), cabi.ptr(r), cabi.ptr(p),
-                               cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part),
-                               cabi.ptr(self.part), s), "dfx_sweep")
+        P = self.plan
+        k = max(1, min(int(slices), P.cpb, cabi.MAX_SLICES)) if P.fast else 1
+        gz = P.n_chunks // P.cpb
+        bounds = [P.cpb * j // k for j in range(k + 1)]
+        vrows = self.v.view(self.M, self.Xs * self.Ys)
+        for j in range(k):
+            c_lo, c_hi = bounds[j], bounds[j + 1]
+            cabi.check(self._timed(f"sweep{mode}", self.lib.dfx_sweep_chunks, mode, g, pl, cabi.ptr(x), cabi.ptr(r),
+                                   cabi.ptr(p), cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part),
+                                   cabi.ptr(self.part), c_lo, c_hi, j, int(j == k - 1), s), "dfx_sweep_chunks")
+            m_lo, m_hi = min(c_lo * P.steps * gz, self.M), min(c_hi * P.steps * gz, self.M)
+            if m_hi <= m_lo:
+                continue
+            if self._v_own is not None:
+                cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), m_lo, m_hi, s),
+                           "dfx_reduce_v")
+            if after_slice is not None:
+                after_slice(vrows[m_lo:m_hi])
         cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
                                          cabi.ptr(self.part), s), "dfx_reduce_u")
-        if self._v_own is not None:
-            cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), s), "dfx_reduce_v")
 
     def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step: int, non_neg: bool) -> None:
         """One fused Adam iteration: x, m1, m2 in place; u(x_new) -> self.u, local v partial -> self.v;
@@ -102,7 +118,8 @@ class HipKernels:
         cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
                                          cabi.ptr(self.part), s), "dfx_reduce_u")
         if self._v_own is not None:
-            cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), s), "dfx_reduce_v")
+            cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), 0, self.M, s),
+                       "dfx_reduce_v")
 
     def sqnorm_v(self) -> None:
         """VV = ||v||^2 (call after the cross-shard sum of v)."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 103
+#define DFX_VERSION 104
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -50,7 +50,7 @@ typedef struct dfx_plan {
     int32_t pad_;
     int64_t u_part_elems;    /* floats: n_chunks * nZ*X*Y */
     int64_t v_part_elems;    /* floats: n_zchunks * nT*nL*Xs*Ys */
-    int64_t part_elems;      /* doubles: max(n_blocks, DFX_EW_MAXBLOCKS) * DFX_NPART */
+    int64_t part_elems;      /* doubles: max(n_blocks * DFX_MAX_SLICES, DFX_EW_MAXBLOCKS) * DFX_NPART */
 } dfx_plan;
 
 /* Slots of the device-resident state `scal` (double[DFX_NSCAL]). */
@@ -75,6 +75,7 @@ enum {
 };
 #define DFX_NPART 4          /* doubles per workgroup row of `part` */
 #define DFX_EW_MAXBLOCKS 2048 /* grid cap of the element-wise kernels */
+#define DFX_MAX_SLICES 16     /* most launches one sweep may be cut into (dfx_sweep_chunks) */
 
 /* sweep modes */
 enum {
@@ -101,6 +102,15 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc, int32
 int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
               double *scal, float *u_part, float *v_part, double *part, void *stream);
 
+/* The same sweep cut along the slab axis, for overlapping the cross-shard sum of v with the rest of the sweep:
+ * launch `slice` (0, 1, ...) handles chunks [c_lo, c_hi) of the plan's cpb, i.e. the contiguous slabs
+ * [c_lo*steps*gz, min(c_hi*steps*gz, nT*nL)) with gz = n_chunks / cpb; when it has run, those rows of v_part
+ * are final.  Slices must be issued in order with increasing `slice`; `last` != 0 on the final one folds the
+ * scalar partials of all slices.  Fast plans only (a generic plan has cpb = 1). */
+int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
+                     double *scal, float *u_part, float *v_part, double *part, int32_t c_lo, int32_t c_hi,
+                     int32_t slice, int32_t last, void *stream);
+
 /* out = (in ? in : 0) + coef * mask * (sa * A[z,x,y] + sb * B[t,l,x/r,y/r]),
  * coef = coef_host * (coef_dev ? *coef_dev : 1); mask (nZ,X,Y) optional (NULL = ones).
  * Broadcast-on-read adjoints: replaces T.T, S.T, D.T (fusion.py:36-42), R.T (fusion.py:78-87),
@@ -125,8 +135,9 @@ int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, fl
 /* u[i] = sum_c u_part[c][i] (i < nZ*X*Y); scal[DFX_S_UU] = sum u^2. */
 int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,
                  double *part, void *stream);
-/* v[i] = sum_zc v_part[zc][i] (i < nT*nL*Xs*Ys). */
-int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, float *v, void *stream);
+/* v[m] = sum_zc v_part[zc][m] for the slabs m_lo <= m < m_hi (rows of Xs*Ys floats). */
+int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, float *v, int64_t m_lo, int64_t m_hi,
+                 void *stream);
 /* scal[slot] = sum_i a[i]^2. */
 int dfx_sqnorm(const float *a, int64_t n, double *scal, int32_t slot, double *part, void *stream);
 /* scal[slot] = w * sum_i mask[i % mask_n] * (a[i] - b[i])^2, mask optional (loss terms,

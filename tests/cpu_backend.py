@@ -32,7 +32,15 @@ class CpuStandIn:
         self.v.copy_(a.sum(2).reshape(n_t, n_l, self.Xs, self.r, self.Ys, self.r).sum((3, 5)))
         self.scal[cabi.S_UU] = (self.u.double() ** 2).sum()
 
-    def sweep(self, mode, x, r=None, p=None):
+    def sweep(self, mode, x, r=None, p=None, slices=1, after_slice=None):
+        self._sweep(mode, x, r, p)
+        if after_slice is not None:           # hand v over in `slices` bands, like the HIP backend
+            rows = self.v.view(self.M, -1)
+            k = max(1, min(slices, self.M))
+            for j in range(k):
+                after_slice(rows[self.M * j // k: self.M * (j + 1) // k])
+
+    def _sweep(self, mode, x, r=None, p=None):
         s = self.scal
         al, be = float(s[cabi.S_ALPHA]), float(s[cabi.S_BETA])
         if mode == cabi.SWEEP_PROJECT:

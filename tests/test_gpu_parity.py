@@ -208,3 +208,27 @@ def test_marginals_on_device(shape):
     assert O.rel_l2(f.marginals("l").cpu(), xd.sum(1)) <= 1e-6
     v = xd.sum(2).reshape(shape[0], shape[1], shape[3] // r, r, shape[3] // r, r).sum((3, 5))
     assert O.rel_l2(f.marginals("zxy").cpu(), v) <= 1e-6
+
+
+def test_sliced_sweep_is_bitwise_identical():
+    """dfx_sweep_chunks: cutting the pass into launches along the slab axis changes nothing."""
+    from datafusion_amd import _cabi as cabi
+    from datafusion_amd.kernels import HipKernels
+    torch.manual_seed(1)
+    shape = (40, 8, 12, 64, 64)
+    k = HipKernels(*shape, 4, DEV, 0, 0, 4)          # steps = 4 -> many chunks per workgroup
+    assert k.plan.fast == 1 and k.plan.cpb >= 4
+    x0, r, p0 = (torch.randn(shape, device=DEV) for _ in range(3))
+    k.scal[cabi.S_ALPHA], k.scal[cabi.S_BETA] = 0.3, 0.7
+    out = []
+    for slices in (1, 3, 16):
+        x, p = x0.clone(), p0.clone()
+        bands = []
+        k.sweep(cabi.SWEEP_XP, x, r, p, slices=slices, after_slice=lambda rows: bands.append(rows.shape[0]))
+        assert sum(bands) == shape[0] * shape[1] and len(bands) == min(slices, k.plan.cpb)
+        out.append((x, p, k.u.clone(), k.v.clone(), k.scal.clone()))
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert torch.equal(a, b)
+    ref_p = r + 0.7 * p0
+    assert O.rel_l2(out[0][1].cpu(), ref_p.cpu()) <= 1e-6
