@@ -1,5 +1,6 @@
 """datafusion_amd - MI355X (gfx950) implementation of the FusionCG hot path of FluoLab/datafusion."""
 from .baseline import baseline
+from .io import load_data
 from .fusion import Fusion, FusionAdam, FusionCG, SumOperator, SumPoolOperator, squared_l2
 
-__all__ = ["baseline", "Fusion", "FusionAdam", "FusionCG", "SumOperator", "SumPoolOperator", "squared_l2"]
+__all__ = ["baseline", "load_data", "Fusion", "FusionAdam", "FusionCG", "SumOperator", "SumPoolOperator", "squared_l2"]

@@ -260,3 +260,28 @@ def test_bench_byte_accounting():
     n = 256 * 16 * 16 * 128 * 128
     assert 32 * n == 34359738368
     assert (5 + 2) * 4 * n == 28 * n
+
+
+def test_load_data_input_stage(tmp_path):
+    """utils.py:411-427 restated without scikit-image (parity unpinned: see datafusion_amd/io.py)."""
+    from datafusion_amd import load_data
+    from datafusion_amd.io import resize_like_skimage
+    rng = np.random.default_rng(0)
+    cmos_file = rng.uniform(0.1, 1.0, (5, 64, 48))              # stored (z, a, b)
+    spc = rng.uniform(0.1, 1.0, (6, 4, 8, 8))
+    path = tmp_path / "acq.npz"
+    np.savez(path, spc=spc, cmos=cmos_file, time_axis=np.arange(6.0), spectral_axis=np.arange(4.0))
+    s, c, t, lam = load_data(path, max_xy_size=32)
+    assert s.shape == spc.shape and np.array_equal(s, spc) and len(t) == 6 and len(lam) == 4
+    assert c.shape == (5, 32, 32)
+    # same-size request is the identity up to the transposes: cmos_out[z, j, i] = cmos_file[z, i, j]
+    sq = rng.uniform(0.1, 1.0, (3, 16, 16))
+    np.savez(path, spc=spc, cmos=sq, time_axis=t, spectral_axis=lam)
+    _, c2, _, _ = load_data(path, max_xy_size=16)
+    assert np.allclose(c2, np.transpose(sq, (0, 2, 1)), atol=1e-12)
+    # shrinking by an integer factor keeps the mean level and smooth ramps (order-1 + anti-aliasing)
+    ramp = np.tile(np.linspace(0, 1, 64)[:, None, None], (1, 64, 2))
+    out = resize_like_skimage(ramp, (16, 16, 2))
+    assert abs(out.mean() - ramp.mean()) < 5e-3 and np.all(np.diff(out[:, 0, 0]) > 0)
+    # and feeds the solver's input contract: (t, l, x/r, y/r) and (z, x, y) with integer r
+    assert c.shape[1] // s.shape[2] == 4 and c.shape[1] % s.shape[2] == 0
