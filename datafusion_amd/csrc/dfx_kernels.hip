@@ -30,11 +30,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef DFX_WAVES
 #define DFX_WAVES 4       // waves per workgroup of the fast kernels (each wave owns one wave tile)
 #endif
+#ifndef DFX_ADAM_ZB
+#define DFX_ADAM_ZB 16     // same for k_adam_fast: all zc planes at once measured best (4.5-4.6 ms at C2)
+#endif
 #ifndef DFX_BCAST_INFLIGHT
 #define DFX_BCAST_INFLIGHT 8  // float4 loads a lane of k_bcast_fast keeps in flight (slabs per trip = this / zc)
 #endif
 #ifndef DFX_ZB
-#define DFX_ZB 4          // z planes whose loads are issued together
+#define DFX_ZB 2          // z planes whose loads are issued together, then updated and stored (finer read/write
+                          // interleaving measured faster: 3.48 / 3.55 / 3.72 ms at 2 / 4 / 8 on the C2 sweep)
 #endif
 
 namespace {
@@ -454,33 +458,38 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
             for (int m = m0; m < m1e; m += gz) {
                 const long long base = (long long)m * a.q.S + off;
                 const float b = a.B[boff + (long long)m * a.q.Ps];
-                f4 xv[ZC], e1[ZC], e2[ZC];
-#pragma unroll
-                for (int k = 0; k < ZC; ++k) {
-                    if (k < zcnt) {
-                        const long long i = base + (long long)k * a.q.P;
-                        xv[k] = ld4s(a.x + i);
-                        e1[k] = ld4s(a.m1 + i);
-                        e2[k] = ld4s(a.m2 + i);
-                    }
-                }
                 f4 s4 = {0.f, 0.f, 0.f, 0.f};
                 float dd = 0.f, xx = 0.f;
+                constexpr int ZB = ZC < DFX_ADAM_ZB ? ZC : DFX_ADAM_ZB;   // planes loaded, updated, stored together
 #pragma unroll
-                for (int k = 0; k < ZC; ++k) {
-                    if (k < zcnt) {
-                        const long long i = base + (long long)k * a.q.P;
-                        f4 g = av[k] + (f4){b, b, b, b};
-                        if (HAS_MASK) g *= mk[k];
-                        const f4 xn = adam_elem4(xv[k], g, e1[k], e2[k], a);
-                        st4s(a.x + i, xn);
-                        st4s(a.m1 + i, e1[k]);
-                        st4s(a.m2 + i, e2[k]);
-                        const f4 d = xn - xv[k];
-                        dd += dot4(d, d);
-                        xx += dot4(xn, xn);
-                        uacc[k] += xn;
-                        s4 += xn;
+                for (int g0 = 0; g0 < ZC; g0 += ZB) {
+                    f4 xv[ZB], e1[ZB], e2[ZB];
+#pragma unroll
+                    for (int j = 0; j < ZB; ++j) {
+                        if (g0 + j < zcnt) {
+                            const long long i = base + (long long)(g0 + j) * a.q.P;
+                            xv[j] = ld4s(a.x + i);
+                            e1[j] = ld4s(a.m1 + i);
+                            e2[j] = ld4s(a.m2 + i);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < ZB; ++j) {
+                        const int k = g0 + j;
+                        if (k < zcnt) {
+                            const long long i = base + (long long)k * a.q.P;
+                            f4 g = av[k] + (f4){b, b, b, b};
+                            if (HAS_MASK) g *= mk[k];
+                            const f4 xn = adam_elem4(xv[j], g, e1[j], e2[j], a);
+                            st4s(a.x + i, xn);
+                            st4s(a.m1 + i, e1[j]);
+                            st4s(a.m2 + i, e2[j]);
+                            const f4 d = xn - xv[j];
+                            dd += dot4(d, d);
+                            xx += dot4(xn, xn);
+                            uacc[k] += xn;
+                            s4 += xn;
+                        }
                     }
                 }
                 float sv = hsum(s4);

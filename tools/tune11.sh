@@ -1,0 +1,9 @@
+set -e
+O=gpurun_out/tune11.txt; rm -f $O
+T="timeout -k 10 280 python -u tools/tune_kernels.py"
+for n in 12 24 48; do
+export DFX_LIB=$PWD/build/libdfx_si$n.so
+$T --zc 8,4 --steps 64 >> $O 2>&1
+$T --shape 64,16,20,128,128 --zc 4 --steps 64 --rounds 8 >> $O 2>&1
+$T --shape 512,32,4,256,256 --zc 4 --steps 64 --rounds 4 >> $O 2>&1
+done
