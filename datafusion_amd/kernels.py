@@ -8,10 +8,23 @@ collective logic can be exercised on CPU (gloo) with a stand-in backend supplied
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import torch
 
 from . import _cabi as cabi
+
+
+def _on_device(fn):
+    """Run a launching method with the shard's GPU current (a stream of cuda:1 cannot be launched on while
+    cuda:0 is the current device); a no-op when it already is."""
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        if torch.cuda.current_device() == self._dev_index:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(self._dev_index):
+            return fn(self, *args, **kwargs)
+    return wrapped
 
 
 class HipKernels:
@@ -21,6 +34,8 @@ class HipKernels:
         if self.device.type != "cuda":
             raise cabi.DfxError(f"datafusion_amd runs on AMD GPUs only (got device={device!r}); there is no CPU path")
         self.lib = cabi.lib()
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self._dev_index)
         self.shape = (n_t, n_l, n_z_local, X, Y)
         self.r = r
         self.M, self.S = n_t * n_l, n_z_local * X * Y
@@ -28,8 +43,9 @@ class HipKernels:
         self.Xs, self.Ys = X // r, Y // r
         self.geom = cabi.Geom(n_t, n_l, n_z_local, X, Y, r, 0)
         self.plan = cabi.Plan()
-        cabi.check(self.lib.dfx_plan_make_ex(C.byref(self.geom), target_blocks, zc, steps, C.byref(self.plan)),
-                   "dfx_plan_make_ex")
+        with torch.cuda.device(self._dev_index):   # the planner sizes the grid to the current device's CU count
+            cabi.check(self.lib.dfx_plan_make_ex(C.byref(self.geom), target_blocks, zc, steps, C.byref(self.plan)),
+                       "dfx_plan_make_ex")
         dev = self.device
         self.scal = torch.zeros(cabi.NSCAL, dtype=torch.float64, device=dev)
         self.part = torch.empty(self.plan.part_elems, dtype=torch.float64, device=dev)
@@ -72,6 +88,7 @@ class HipKernels:
                 assert t.device == self.scal.device and t.dtype == torch.float32 and t.is_contiguous()
 
     # -- 5-D passes -----------------------------------------------------------------------
+    @_on_device
     def sweep(self, mode: int, x, r=None, p=None, slices: int = 1, after_slice=None) -> None:
         """u(.) -> self.u (+UU), local v partial -> self.v, PP/XX/XP -> scal.
         slices > 1 cuts the pass along the slab axis into that many launches (fast plans; at most cpb);
@@ -103,6 +120,7 @@ class HipKernels:
         cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
                                          cabi.ptr(self.part), s), "dfx_reduce_u")
 
+    @_on_device
     def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step: int, non_neg: bool) -> None:
         """One fused Adam iteration: x, m1, m2 in place; u(x_new) -> self.u, local v partial -> self.v;
         ADAM_DD = ||dx||^2, ADAM_XX = ||x_new||^2."""
@@ -121,11 +139,13 @@ class HipKernels:
             cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), 0, self.M, s),
                        "dfx_reduce_v")
 
+    @_on_device
     def sqnorm_v(self) -> None:
         """VV = ||v||^2 (call after the cross-shard sum of v)."""
         cabi.check(self.lib.dfx_sqnorm(cabi.ptr(self.v), self.v.numel(), cabi.ptr(self.scal), cabi.S_VV,
                                        cabi.ptr(self.part), self._stream()), "dfx_sqnorm")
 
+    @_on_device
     def bcast(self, out, inp, A, B, mask, sa: float, sb: float, coef_host: float, coef_slot: int | None) -> None:
         """out = inp + coef*mask*(sa*A[z,x,y] + sb*B[t,l,x/r,y/r]); RR = sum(out^2)."""
         self._chk(out, inp, A, B, mask)
@@ -138,6 +158,7 @@ class HipKernels:
                                None if coef_slot is None else self.slot_ptr(coef_slot),
                                cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_bcast")
 
+    @_on_device
     def axpy(self, y, x, coef_host: float, coef_slot: int | None) -> None:
         """y += coef * x ; XXNEW = ||y||^2."""
         self._chk(y, x)
@@ -146,18 +167,21 @@ class HipKernels:
                                      None if coef_slot is None else self.slot_ptr(coef_slot), cabi.ptr(self.scal),
                                      cabi.ptr(self.part), self._stream()), "dfx_axpy")
 
+    @_on_device
     def scale(self, y, mask, coef_host: float, coef_slot: int | None) -> None:
         self._chk(y, mask)
         cabi.check(self.lib.dfx_scale(cabi.ptr(y), y.numel(), cabi.ptr(mask), 0 if mask is None else mask.numel(),
                                       coef_host, None if coef_slot is None else self.slot_ptr(coef_slot),
                                       self._stream()), "dfx_scale")
 
+    @_on_device
     def sum(self, y) -> None:
         """SUM = sum(y)."""
         self._chk(y)
         cabi.check(self.lib.dfx_sum(cabi.ptr(y), y.numel(), cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()),
                    "dfx_sum")
 
+    @_on_device
     def sum_axis(self, x, axis: int):
         """x.sum(axis) for axis 0 (time) or 1 (lambda) of the local (t, l, z, x, y) shard -> new tensor."""
         self._chk(x)
@@ -172,10 +196,12 @@ class HipKernels:
         cabi.check(self.lib.dfx_sum_axis(cabi.ptr(x), cabi.ptr(out), A, R, B, self._stream()), "dfx_sum_axis")
         return out
 
+    @_on_device
     def recip(self, dst_slot: int, src_slot: int, num: float) -> None:
         cabi.check(self.lib.dfx_recip(self.slot_ptr(dst_slot), self.slot_ptr(src_slot), num, self._stream()),
                    "dfx_recip")
 
+    @_on_device
     def sqdiff(self, a, b, mask, w: float, slot: int) -> None:
         """scal[slot] = w * sum mask*(a-b)^2 (mask periodic over the flat index)."""
         self._chk(a, b, mask)
@@ -184,6 +210,7 @@ class HipKernels:
                                        a.numel(), w, cabi.ptr(self.scal), slot, cabi.ptr(self.part), self._stream()),
                    "dfx_sqdiff")
 
+    @_on_device
     def baseline_init(self, spc, zw, x, coef_host: float, coef_slot: int | None) -> None:
         """x = coef * up(spc) * zw (x may be None: SUM only)."""
         self._chk(spc, zw, x)
@@ -195,11 +222,14 @@ class HipKernels:
                    "dfx_baseline_init")
 
     # -- scalar bookkeeping ---------------------------------------------------------------
+    @_on_device
     def cg_start(self) -> None:
         cabi.check(self.lib.dfx_cg_start(cabi.ptr(self.scal), self._stream()), "dfx_cg_start")
 
+    @_on_device
     def cg_alpha(self, c1: float, c2: float, eps: float) -> None:
         cabi.check(self.lib.dfx_cg_alpha(cabi.ptr(self.scal), c1, c2, eps, self._stream()), "dfx_cg_alpha")
 
+    @_on_device
     def cg_beta(self, eps: float, deferred: bool) -> None:
         cabi.check(self.lib.dfx_cg_beta(cabi.ptr(self.scal), eps, int(deferred), self._stream()), "dfx_cg_beta")
