@@ -396,15 +396,15 @@ struct AdamArgs {
     const float *A, *B, *mask;
     float *u_part, *v_part;
     double *part;
-    float b1, b2, eps, step_size, inv_sqrt_bc2;
+    float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2;   // omb = 1 - beta, rounded from double like torch
     int non_neg;
     Geo q;
     int steps, cpb;
 };
 
 __device__ __forceinline__ float adam_elem(float x, float g, float &m1, float &m2, const AdamArgs &a) {
-    m1 = m1 + (1.f - a.b1) * (g - m1);                    // exp_avg.lerp_(grad, 1 - beta1)
-    m2 = a.b2 * m2 + (1.f - a.b2) * (g * g);              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m1 = m1 + a.omb1 * (g - m1);                          // exp_avg.lerp_(grad, 1 - beta1)
+    m2 = a.b2 * m2 + a.omb2 * (g * g);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = __fsqrt_rn(m2) * a.inv_sqrt_bc2 + a.eps;
     float xn = x - a.step_size * __fdiv_rn(m1, denom);    // param.addcdiv_(exp_avg, denom, value=-step_size)
     if (a.non_neg) xn = fmaxf(xn, 0.f);                   // fusion.py:344-346
@@ -1092,7 +1092,8 @@ int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, fl
         return fail(DFX_EINVAL, "dfx_adam_step: step >= 1 and betas in [0, 1) required");
     hipStream_t st = (hipStream_t)stream;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    AdamArgs a{x, m1, m2, A, B, mask, u_part, v_part, part, (float)beta1, (float)beta2, (float)eps,
+    AdamArgs a{x, m1, m2, A, B, mask, u_part, v_part, part, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+               (float)(1.0 - beta2), (float)eps,
                (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), non_neg ? 1 : 0, q, pl->steps, pl->cpb};
     int n_rows;
     if (pl->fast) {

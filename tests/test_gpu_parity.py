@@ -232,3 +232,82 @@ def test_sliced_sweep_is_bitwise_identical():
             assert torch.equal(a, b)
     ref_p = r + 0.7 * p0
     assert O.rel_l2(out[0][1].cpu(), ref_p.cpu()) <= 1e-6
+
+
+@pytest.mark.parametrize("dims", [(5, 3, 7, 64, 128), (1, 1, 1, 12, 64), (2, 1, 9, 20, 192), (3, 2, 4, 4, 64),
+                                  (70, 3, 5, 8, 64), (2, 2, 3, 12, 20)])
+def test_kernels_on_ragged_and_nonsquare_geometries(dims):
+    """Every 5-D kernel against torch float64 formulas on shapes the solver tests cannot reach (X != Y, one wave
+    tile, inactive waves in the last workgroup, fewer slabs than workgroups, ragged z-chunks; last: generic path)."""
+    from datafusion_amd import _cabi as cabi
+    from datafusion_amd.kernels import HipKernels
+    torch.manual_seed(2)
+    n_t, n_l, n_z, X, Y = dims
+    r = 4
+    k = HipKernels(n_t, n_l, n_z, X, Y, r, DEV)
+    assert k.plan.fast == (1 if Y % 64 == 0 else 0)
+    x, rr, p = (torch.randn(k.shape, device=DEV) for _ in range(3))
+    al, be = 0.37, -0.61
+    k.scal[cabi.S_ALPHA], k.scal[cabi.S_BETA] = al, be
+    xd, rd, pd = x.double(), rr.double(), p.double()
+
+    def proj(a):
+        return a.sum((0, 1)), a.sum(2).reshape(n_t, n_l, X // r, r, Y // r, r).sum((3, 5))
+
+    # sweep XP
+    x1, p1 = x.clone(), p.clone()
+    k.sweep(cabi.SWEEP_XP, x1, rr, p1)
+    xn, pn = xd + al * pd, rd + be * pd
+    u, v = proj(pn)
+    s = k.scal.cpu()
+    assert O.rel_l2(x1.cpu(), xn.cpu()) <= 1e-6 and O.rel_l2(p1.cpu(), pn.cpu()) <= 1e-6
+    assert O.rel_l2(k.u.cpu(), u.cpu()) <= 1e-6 and O.rel_l2(k.v.cpu(), v.cpu()) <= 1e-6
+    for slot, ref in ((cabi.S_PP, (pn ** 2).sum()), (cabi.S_XX, (xn ** 2).sum()), (cabi.S_XP, (xn * pn).sum()),
+                      (cabi.S_UU, (u ** 2).sum())):
+        assert abs(float(s[slot]) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), slot
+    # sweep P and PINIT
+    p2 = p.clone()
+    k.sweep(cabi.SWEEP_P, x, rr, p2)
+    assert O.rel_l2(p2.cpu(), pn.cpu()) <= 1e-6
+    p3 = torch.full_like(p, float("nan"))
+    k.sweep(cabi.SWEEP_PINIT, x, rr, p3)
+    assert torch.equal(p3, rr)
+    # bcast with input, coefficient from the device, mask
+    A = torch.randn(n_z, X, Y, device=DEV)
+    B = torch.randn(n_t, n_l, X // r, Y // r, device=DEV)
+    mask = (torch.rand(n_z, X, Y, device=DEV) > 0.3).float()
+    for inp, mk in ((rr, None), (None, mask), (rr, mask)):
+        out = torch.empty_like(x)
+        k.bcast(out, inp, A, B, mk, 0.7, -1.3, -1.0, cabi.S_ALPHA)
+        ref = (-al) * (0.7 * A.double()[None, None] + (-1.3) * B.double().repeat_interleave(r, 2)
+                       .repeat_interleave(r, 3)[:, :, None])
+        if mk is not None:
+            ref = ref * mk.double()[None, None]
+        if inp is not None:
+            ref = ref + inp.double()
+        assert O.rel_l2(out.cpu(), ref.cpu()) <= 1e-6
+        assert abs(float(k.scal[cabi.S_RR]) - float((ref ** 2).sum())) <= 2e-6 * float((ref ** 2).sum())
+    # fused Adam step against torch.optim.Adam's formulas
+    m1, m2 = torch.randn_like(x) * 0.1, torch.rand_like(x) * 0.01
+    x4, m14, m24 = x.clone(), m1.clone(), m2.clone()
+    k.adam_step(x4, m14, m24, A, B, mask, 1e-2, 0.9, 0.999, 1e-8, 3, True)
+    g = (A[None, None] + B.repeat_interleave(r, 2).repeat_interleave(r, 3)[:, :, None]) * mask[None, None]
+    e1 = m1.lerp(g, 0.1)
+    e2 = m2 * 0.999 + 0.001 * g * g
+    xr = (x - (1e-2 / (1 - 0.9 ** 3)) * e1 / (e2.sqrt() / (1 - 0.999 ** 3) ** 0.5 + 1e-8)).clamp(min=0)
+    assert O.rel_l2(x4.cpu(), xr.cpu()) <= 1e-5 and O.rel_l2(m14.cpu(), e1.cpu()) <= 1e-6
+    assert O.rel_l2(m24.cpu(), e2.cpu()) <= 1e-6
+    u4, v4 = proj(x4.double())
+    assert O.rel_l2(k.u.cpu(), u4.cpu()) <= 1e-6 and O.rel_l2(k.v.cpu(), v4.cpu()) <= 1e-6
+    # axis sums
+    assert O.rel_l2(k.sum_axis(x, 0).cpu(), xd.sum(0).cpu()) <= 1e-6
+    assert O.rel_l2(k.sum_axis(x, 1).cpu(), xd.sum(1).cpu()) <= 1e-6
+    # baseline initialiser against F.interpolate (what the reference's Resize does for up-sampling)
+    spc = torch.rand(n_t, n_l, X // r, Y // r, device=DEV) + 0.1
+    zw = torch.rand(n_z, X, Y, device=DEV)
+    xb = torch.empty_like(x)
+    k.baseline_init(spc, zw, xb, 1.0, None)
+    up = torch.nn.functional.interpolate(spc.cpu(), size=(X, Y), mode="bilinear", align_corners=False)
+    ref = up[:, :, None] * zw.cpu()[None, None]
+    assert O.rel_l2(xb.cpu(), ref) <= 1e-6
+    assert abs(float(k.scal[cabi.S_SUM]) - float(ref.double().sum())) <= 1e-6 * float(ref.double().sum())
