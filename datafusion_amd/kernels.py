@@ -2,7 +2,7 @@
 
 Every method enqueues kernels on torch's current HIP stream of `device` and returns without
 synchronising.  The CG scalars live in `self.scal` (double[NSCAL]) on the device.
-The orchestration in solver.py is written against this small interface so that its sharding /
+The orchestration in fusion.py is written against this small interface so that its sharding /
 collective logic can be exercised on CPU (gloo) with a stand-in backend supplied by the tests.
 """
 from __future__ import annotations
