@@ -285,3 +285,16 @@ def test_load_data_input_stage(tmp_path):
     assert abs(out.mean() - ramp.mean()) < 5e-3 and np.all(np.diff(out[:, 0, 0]) > 0)
     # and feeds the solver's input contract: (t, l, x/r, y/r) and (z, x, y) with integer r
     assert c.shape[1] // s.shape[2] == 4 and c.shape[1] % s.shape[2] == 0
+
+
+def test_integration_doc_struct_layout_matches_header():
+    """The ctypes stub printed in INTEGRATION.md must lay dfx_plan out like include/dfx.h."""
+    from datafusion_amd import _cabi as cabi
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r'for n in \(("fast".*?)\)\] \+', doc, flags=re.S)
+    names32 = re.findall(r'"(\w+)"', m.group(1))
+    assert names32 == [f[0] for f in cabi.Plan._fields_ if f[1] is C.c_int32]
+    hdr = open(os.path.join(ROOT, "include", "dfx.h")).read()
+    body = re.search(r"typedef struct dfx_plan \{(.*?)\} dfx_plan;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    assert re.findall(r"int(?:32|64)_t\s+(\w+);", body) == [f[0] for f in cabi.Plan._fields_]
