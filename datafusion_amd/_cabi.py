@@ -60,6 +60,9 @@ SIGNATURES = {
     "dfx_sum": [_P, _i64, _P, _P, _P],
     "dfx_recip": [_P, _P, _d, _P],
     "dfx_sum_axis": [_P, _P, _i64, _i64, _i64, _P],
+    "dfx_expand_axis": [_P, _P, _i64, _i64, _i64, _f, _P],
+    "dfx_block_sum": [_P, _P, _i64, _i64, _i64, _i32, _P],
+    "dfx_block_expand": [_P, _P, _i64, _i64, _i64, _i32, _f, _P],
     "dfx_baseline_init": [_G, _P, _P, _P, _f, _P, _P, _P, _P],
 }
 

@@ -772,6 +772,46 @@ __global__ __launch_bounds__(256) void k_sum_axis(const float *x, float *out, lo
     }
 }
 
+// Stand-alone operator kernels behind the SumOperator / SumPoolOperator API mirrors (fusion.py:21-98).  The solvers
+// never launch these (their work is fused into k_sweep_fast / k_bcast_fast); they exist so that T, S, D, R and
+// their normalised transposes are callable on device tensors exactly like the reference's objects.
+// out[(a*R + k)*B + b] = scale * y[a*B + b]   (repeat_interleave(R, dim) / size, fusion.py:42)
+__global__ __launch_bounds__(256) void k_expand_axis(const float *y, float *out, long long A, long long R, long long B,
+                                                     float scale) {
+    const long long n = A * R * B, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long b = i % B, a = i / (R * B);
+        out[i] = scale * y[a * B + b];
+    }
+}
+
+// out[row][xb][yb] = sum_{r x r} in[row][xb*r + dx][yb*r + dy]   (depthwise ones conv, stride r, fusion.py:95-97)
+__global__ __launch_bounds__(256) void k_block_sum(const float *in, float *out, long long rows, int X, int Y, int r) {
+    const int Xs = X / r, Ys = Y / r;
+    const long long n = rows * Xs * Ys, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int yb = (int)(i % Ys), xb = (int)((i / Ys) % Xs);
+        const long long row = i / ((long long)Xs * Ys);
+        const float *src = in + row * X * Y + (long long)xb * r * Y + (long long)yb * r;
+        float s = 0.f;
+        for (int dx = 0; dx < r; ++dx)
+            for (int dy = 0; dy < r; ++dy) s += src[(long long)dx * Y + dy];
+        out[i] = s;
+    }
+}
+
+// out[row][x][y] = scale * in[row][x/r][y/r]   (conv_transpose2d with the ones kernel / r^2, fusion.py:84-87)
+__global__ __launch_bounds__(256) void k_block_expand(const float *in, float *out, long long rows, int X, int Y, int r,
+                                                      float scale) {
+    const int Xs = X / r, Ys = Y / r;
+    const long long n = rows * X * Y, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i % Y), x = (int)((i / Y) % X);
+        const long long row = i / ((long long)X * Y);
+        out[i] = scale * in[row * Xs * Ys + (long long)(x / r) * Ys + y / r];
+    }
+}
+
 struct BaseArgs {
     const float *spc;
     const float *zw;
@@ -1236,6 +1276,33 @@ int dfx_sum_axis(const float *x, float *out, int64_t A, int64_t R, int64_t B, vo
     hipLaunchKernelGGL(k_sum_axis, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, out, (long long)A,
                        (long long)R, (long long)B);
     DFX_LAUNCH_CHECK("dfx_sum_axis");
+    return 0;
+}
+
+int dfx_expand_axis(const float *y, float *out, int64_t A, int64_t R, int64_t B, float scale, void *stream) {
+    if (!y || !out || A <= 0 || R <= 0 || B <= 0) return fail(DFX_EINVAL, "dfx_expand_axis: bad argument");
+    hipLaunchKernelGGL(k_expand_axis, dim3(ew_blocks(A * R * B, 4)), dim3(256), 0, (hipStream_t)stream, y, out,
+                       (long long)A, (long long)R, (long long)B, scale);
+    DFX_LAUNCH_CHECK("dfx_expand_axis");
+    return 0;
+}
+
+int dfx_block_sum(const float *in, float *out, int64_t rows, int64_t X, int64_t Y, int32_t r, void *stream) {
+    if (!in || !out || rows <= 0 || X <= 0 || Y <= 0 || r <= 0 || X % r || Y % r || X > 0x7fffffff || Y > 0x7fffffff)
+        return fail(DFX_EINVAL, "dfx_block_sum: bad argument");
+    hipLaunchKernelGGL(k_block_sum, dim3(ew_blocks(rows * (X / r) * (Y / r), 1)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, (long long)rows, (int)X, (int)Y, (int)r);
+    DFX_LAUNCH_CHECK("dfx_block_sum");
+    return 0;
+}
+
+int dfx_block_expand(const float *in, float *out, int64_t rows, int64_t X, int64_t Y, int32_t r, float scale,
+                     void *stream) {
+    if (!in || !out || rows <= 0 || X <= 0 || Y <= 0 || r <= 0 || X % r || Y % r || X > 0x7fffffff || Y > 0x7fffffff)
+        return fail(DFX_EINVAL, "dfx_block_expand: bad argument");
+    hipLaunchKernelGGL(k_block_expand, dim3(ew_blocks(rows * X * Y, 4)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       (long long)rows, (int)X, (int)Y, (int)r, scale);
+    DFX_LAUNCH_CHECK("dfx_block_expand");
     return 0;
 }
 

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from . import _cabi as cabi
 from .dist import ShardComm, z_partition
+from . import kernels
 from .kernels import HipKernels
 
 
@@ -33,8 +34,8 @@ def squared_l2(x):
 
 
 class SumOperator:
-    """API mirror of fusion.py:21-51 (T, S, D as stand-alone callables on torch tensors).
-    The solvers never call these: the sums are fused into dfx_sweep and the normalised
+    """API mirror of fusion.py:21-51: T, S, D as stand-alone callables on device tensors (dfx_sum_axis /
+    dfx_expand_axis).  The solvers never call these: the sums are fused into dfx_sweep and the normalised
     transposes are broadcast-on-read inside dfx_bcast."""
 
     def __init__(self, size: int = 1, integral_dim: int = 0):
@@ -42,31 +43,26 @@ class SumOperator:
         self.integral_dim = integral_dim
 
     def T(self, y: torch.Tensor) -> torch.Tensor:
-        shape = list(y.shape)
-        shape[self.integral_dim] *= self.size
-        return (y / self.size).unsqueeze(self.integral_dim + 1).expand(
-            *y.shape[: self.integral_dim + 1], self.size, *y.shape[self.integral_dim + 1:]).reshape(shape)
+        return kernels.op_expand_axis(y, int(self.size), self.integral_dim)      # fusion.py:42
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         self.size = x.shape[self.integral_dim]  # fusion.py:50
-        return x.sum(dim=self.integral_dim, keepdim=True)
+        return kernels.op_sum_axis(x, self.integral_dim)                         # fusion.py:51
 
 
 class SumPoolOperator:
-    """API mirror of fusion.py:54-98 (R and its normalised transpose) on (nT, nL, 1, X, Y) tensors."""
+    """API mirror of fusion.py:54-98 (R and its normalised transpose) on (nT, nL, 1, X, Y) device tensors
+    (dfx_block_sum / dfx_block_expand)."""
 
     def __init__(self, size: int = 4, channels: int = 16, device: str = "cuda"):
         self.size = size
         self.channels = channels
 
     def T(self, y: torch.Tensor) -> torch.Tensor:
-        r = self.size
-        return (y / r ** 2).repeat_interleave(r, dim=-2).repeat_interleave(r, dim=-1)
+        return kernels.op_block_expand(y, int(self.size))                        # fusion.py:84-87
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        r = self.size
-        s = x.shape
-        return x.reshape(*s[:-2], s[-2] // r, r, s[-1] // r, r).sum(dim=(-3, -1))
+        return kernels.op_block_sum(x, int(self.size))                           # fusion.py:95-97
 
 
 class Fusion:

@@ -233,3 +233,62 @@ class HipKernels:
     @_on_device
     def cg_beta(self, eps: float, deferred: bool) -> None:
         cabi.check(self.lib.dfx_cg_beta(cabi.ptr(self.scal), eps, int(deferred), self._stream()), "dfx_cg_beta")
+
+
+# ---- stand-alone operator launches (SumOperator / SumPoolOperator mirrors) -------------------------------------
+def _prep(t: torch.Tensor) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise cabi.DfxError("datafusion_amd operators run on AMD GPU tensors only; there is no CPU path")
+    return t.detach().float().contiguous()
+
+
+def _prod(xs) -> int:
+    n = 1
+    for v in xs:
+        n *= int(v)
+    return n
+
+
+def op_sum_axis(x: torch.Tensor, dim: int) -> torch.Tensor:
+    """x.sum(dim, keepdim=True) through dfx_sum_axis."""
+    x = _prep(x)
+    shape = list(x.shape)
+    A, R, B = _prod(shape[:dim]), shape[dim], _prod(shape[dim + 1:])
+    out = torch.empty(shape[:dim] + [1] + shape[dim + 1:], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        cabi.check(cabi.lib().dfx_sum_axis(cabi.ptr(x), cabi.ptr(out), A, R, B,
+                                           torch.cuda.current_stream(x.device).cuda_stream), "dfx_sum_axis")
+    return out
+
+
+def op_expand_axis(y: torch.Tensor, size: int, dim: int) -> torch.Tensor:
+    """y.repeat_interleave(size, dim) / size through dfx_expand_axis."""
+    y = _prep(y)
+    shape = list(y.shape)
+    A, R0, B = _prod(shape[:dim]), shape[dim], _prod(shape[dim + 1:])
+    # each of the R0 entries along dim is repeated `size` times: (A*R0, size, B)
+    out = torch.empty(shape[:dim] + [R0 * size] + shape[dim + 1:], dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        cabi.check(cabi.lib().dfx_expand_axis(cabi.ptr(y), cabi.ptr(out), A * R0, size, B, 1.0 / size,
+                                              torch.cuda.current_stream(y.device).cuda_stream), "dfx_expand_axis")
+    return out
+
+
+def op_block_sum(x: torch.Tensor, r: int) -> torch.Tensor:
+    x = _prep(x)
+    X, Y = int(x.shape[-2]), int(x.shape[-1])
+    out = torch.empty(list(x.shape[:-2]) + [X // r, Y // r], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        cabi.check(cabi.lib().dfx_block_sum(cabi.ptr(x), cabi.ptr(out), _prod(x.shape[:-2]), X, Y, r,
+                                            torch.cuda.current_stream(x.device).cuda_stream), "dfx_block_sum")
+    return out
+
+
+def op_block_expand(y: torch.Tensor, r: int) -> torch.Tensor:
+    y = _prep(y)
+    X, Y = int(y.shape[-2]) * r, int(y.shape[-1]) * r
+    out = torch.empty(list(y.shape[:-2]) + [X, Y], dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        cabi.check(cabi.lib().dfx_block_expand(cabi.ptr(y), cabi.ptr(out), _prod(y.shape[:-2]), X, Y, r, 1.0 / (r * r),
+                                               torch.cuda.current_stream(y.device).cuda_stream), "dfx_block_expand")
+    return out

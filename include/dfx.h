@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 104
+#define DFX_VERSION 105
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -168,6 +168,15 @@ int dfx_sum(const float *y, int64_t n, double *scal, double *part, void *stream)
  * solve - x.sum(axis=0): A=1, R=nT; x.sum(axis=1): A=nT, R=nL (analysis/cells.ipynb cell 27bf9830e81df430) -
  * computed on the device so the 5-D volume need not cross PCIe (fusion.py:489-493 returns it whole). */
 int dfx_sum_axis(const float *x, float *out, int64_t A, int64_t R, int64_t B, void *stream);
+/* Stand-alone forms of the reference's operator objects (the solvers use the fused kernels above instead):
+ * dfx_sum_axis is SumOperator.__call__ (fusion.py:44-51);
+ * dfx_expand_axis is SumOperator.T (fusion.py:36-42): out[(a*R + k)*B + b] = scale * y[a*B + b], scale = 1/size;
+ * dfx_block_sum is SumPoolOperator.__call__ (fusion.py:89-98): r x r block sums of `rows` planes of X x Y;
+ * dfx_block_expand is SumPoolOperator.T (fusion.py:78-87): out[row][x][y] = scale * in[row][x/r][y/r], scale = 1/r^2. */
+int dfx_expand_axis(const float *y, float *out, int64_t A, int64_t R, int64_t B, float scale, void *stream);
+int dfx_block_sum(const float *in, float *out, int64_t rows, int64_t X, int64_t Y, int32_t r, void *stream);
+int dfx_block_expand(const float *in, float *out, int64_t rows, int64_t X, int64_t Y, int32_t r, float scale,
+                     void *stream);
 /* dst[0] = num / src[0]  (device scalars; total_energy / sum, fusion.py:209). */
 int dfx_recip(double *dst, const double *src, double num, void *stream);
 

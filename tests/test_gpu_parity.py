@@ -311,3 +311,27 @@ def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     ref = up[:, :, None] * zw.cpu()[None, None]
     assert O.rel_l2(xb.cpu(), ref) <= 1e-6
     assert abs(float(k.scal[cabi.S_SUM]) - float(ref.double().sum())) <= 1e-6 * float(ref.double().sum())
+
+
+def test_operator_mirrors_match_reference_semantics():
+    """T, S, D, R objects of a Fusion instance behave like fusion.py:21-98 on device tensors, and A(x) built from
+    them as the reference's closure does (fusion.py:423-426) equals the oracle's normal operator."""
+    from datafusion_amd import FusionCG, SumOperator, SumPoolOperator
+    torch.manual_seed(3)
+    x = torch.randn(3, 4, 5, 8, 8)
+    xg = x.to(DEV)
+    for dim in range(3):
+        op = SumOperator(size=1, integral_dim=dim)
+        y = op(xg)
+        assert op.size == x.shape[dim] and O.rel_l2(y.cpu(), O.sum_keep(x, dim)) <= 1e-6
+        assert O.rel_l2(op.T(y).cpu(), O.spread_mean(O.sum_keep(x, dim), x.shape[dim], dim)) <= 1e-6
+    R = SumPoolOperator(size=4, channels=4)
+    d = O.sum_keep(x, 2)
+    assert O.rel_l2(R(d.to(DEV)).cpu(), O.block_sum(d, 4)) <= 1e-6
+    assert O.rel_l2(R.T(R(d.to(DEV))).cpu(), O.block_spread(O.block_sum(d, 4), 4)) <= 1e-6
+    spc, cmos = O.synthetic_inputs(3, 4, 5, 8, 4)
+    w = {"spatial": 0.3, "spectro_temporal": 0.7}
+    f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV)
+    a = 0.3 * f.T.T(f.S.T(f.S(f.T(xg)))) + 0.7 * f.D.T(f.R.T(f.R(f.D(xg))))
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
+    assert O.rel_l2(a.cpu(), O.normal_op(pb, x)) <= 1e-6
