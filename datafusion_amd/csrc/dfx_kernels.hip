@@ -2,14 +2,14 @@
 // C ABI in include/dfx.h.  Everything here is HBM-bandwidth-bound fp32 streaming + reductions:
 // no MFMA.  The 5-D vectors x, r, p (layout (t, l, z, x, y), y contiguous) are swept by
 // workgroups of four 64-lane waves; each wave owns a "wave tile" of 4 rows x 64 columns
-// (one row of sixteen 4x4 downsampling blocks), each lane a float4 (one block row), for `zc`
+// (sixteen consecutive 4x4 downsampling blocks), each lane a float4 (one block row), for `zc`
 // z-planes held in registers and a chunk of `steps` consecutive (t,l) slabs:
 //   * u = sum_{t,l} (fusion.py:44-51, T and S) accumulates in zc float4 registers per lane and is
 //     written once per workgroup to u_part[chunk];
 //   * v = sum_z sum_{4x4} (fusion.py:44-51 D, fusion.py:89-98 R) is a lane-local sum over z and
 //     the float4, then two cross-lane adds (lanes l, l^16, l^32, l^48 hold the 4 rows of a block).
 // No LDS tile and no barrier in the streaming loop; LDS is only used for the per-workgroup
-// scalar partials.  Shapes that do not fit (r != 4 or Y % 64 != 0) take the generic kernels.
+// scalar partials.  r != 4 takes the generic kernels.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -66,8 +66,8 @@ struct Geo {
     long long N;   // M*S
     int M;         // nT*nL
     int nZ, X, Y, Xs, Ys, r;
-    int WT;        // wave tiles per plane (fast path)
-    int tiles_y;   // Y/64
+    int WT;        // wave tiles per plane (fast path): ceil(nblk / 16)
+    int nblk;      // r x r blocks per plane = Xs*Ys
 };
 
 int make_geo(const dfx_geom *g, Geo *o) {
@@ -90,12 +90,13 @@ int make_geo(const dfx_geom *g, Geo *o) {
     o->S = o->P * o->nZ;
     o->N = o->S * M;
     if (o->S > 0x7fffffffLL) return fail(DFX_EINVAL, "one (t,l) slab must stay below 2^31 elements");
-    o->tiles_y = o->Y / 64;
-    o->WT = (o->X / 4) * (o->Y / 64);
+    o->nblk = o->Xs * o->Ys;
+    o->WT = (o->nblk + 15) / 16;
     return 0;
 }
 
-bool fast_ok(const Geo &q) { return q.r == 4 && q.Y % 64 == 0; }
+// r = 4 (then X, Y are multiples of 4: rows are 16-byte aligned and a float4 is one block row)
+bool fast_ok(const Geo &q) { return q.r == 4; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -251,13 +252,15 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
     const int zcnt = min(ZC, a.q.nZ - z0);
     const int gz = gridDim.z, bz = blockIdx.z;
     double dpp = 0, dxx = 0, dxp = 0;
-    if (wt < a.q.WT) {  // wave-uniform
-        const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
-        const int row = tx * 4 + (lane >> 4);
-        const int col = ty * 64 + (lane & 15) * 4;
+    // a wave owns 16 consecutive 4x4 blocks of the plane (row-major over (x/4, y/4)); lanes l, l^16, l^32, l^48
+    // hold the four rows of block (l & 15).  Only the last wave of a plane can have idle lanes.
+    const int blk = wt * 16 + (lane & 15);
+    if (blk < a.q.nblk) {
+        const int xb = blk / a.q.Ys, yb = blk - xb * a.q.Ys;
+        const int row = xb * 4 + (lane >> 4);
+        const int col = yb * 4;
         const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
-        const long long voff =
-            (long long)blockIdx.y * a.q.M * a.q.Ps + (long long)tx * a.q.Ys + ty * 16 + (lane & 15);
+        const long long voff = (long long)blockIdx.y * a.q.M * a.q.Ps + blk;
         const float fa = (MODE == DFX_SWEEP_XP) ? (float)a.scal[DFX_S_ALPHA] : 0.f;
         const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)a.scal[DFX_S_BETA] : 0.f;
         for (int c = a.c_lo; c < a.c_hi; ++c) {
@@ -353,12 +356,13 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(con
     const int zcnt = min(ZC, a.q.nZ - z0);
     const int m0 = blockIdx.z, ms = gridDim.z, m1 = a.q.M;
     double drr = 0;
-    if (wt < a.q.WT) {
-        const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
-        const int row = tx * 4 + (lane >> 4);
-        const int col = ty * 64 + (lane & 15) * 4;
+    const int blk = wt * 16 + (lane & 15);
+    if (blk < a.q.nblk) {
+        const int xb = blk / a.q.Ys, yb = blk - xb * a.q.Ys;
+        const int row = xb * 4 + (lane >> 4);
+        const int col = yb * 4;
         const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
-        const long long boff = (long long)tx * a.q.Ys + ty * 16 + (lane & 15);
+        const long long boff = blk;
         const float coef = a.coef_host * (a.coef_dev ? (float)(*a.coef_dev) : 1.f);
         const float ca = coef * a.sa, cb = coef * a.sb;
         f4 av[ZC], mk[ZC];
@@ -432,12 +436,13 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
     const int zcnt = min(ZC, a.q.nZ - z0);
     const int gz = gridDim.z, bz = blockIdx.z;
     double ddd = 0, dxx = 0;
-    if (wt < a.q.WT) {
-        const int ty = wt % a.q.tiles_y, tx = wt / a.q.tiles_y;
-        const int row = tx * 4 + (lane >> 4);
-        const int col = ty * 64 + (lane & 15) * 4;
+    const int blk = wt * 16 + (lane & 15);
+    if (blk < a.q.nblk) {
+        const int xb = blk / a.q.Ys, yb = blk - xb * a.q.Ys;
+        const int row = xb * 4 + (lane >> 4);
+        const int col = yb * 4;
         const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
-        const long long boff = (long long)tx * a.q.Ys + ty * 16 + (lane & 15);
+        const long long boff = blk;
         const long long voff = (long long)blockIdx.y * a.q.M * a.q.Ps + boff;
         f4 av[ZC], mk[ZC];
 #pragma unroll

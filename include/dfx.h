@@ -38,7 +38,7 @@ typedef struct dfx_geom {
 } dfx_geom;
 
 /* Launch plan + workspace sizes for one geometry.  fast=1: float4 wave-tile kernels
- * (r == 4, Y % 64 == 0); fast=0: shape-generic kernels. */
+ * (r == 4); fast=0: shape-generic kernels (any r). */
 typedef struct dfx_plan {
     int32_t fast;
     int32_t zc;          /* z planes a workgroup keeps in registers */

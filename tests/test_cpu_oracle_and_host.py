@@ -131,7 +131,7 @@ def test_header_constants_match_python_mirror():
 
 
 @pytest.mark.parametrize("dims,fast", [((256, 16, 16, 128, 128, 4), 1), ((512, 32, 4, 256, 256, 4), 1),
-                                       ((64, 16, 20, 128, 128, 4), 1), ((8, 4, 4, 32, 32, 4), 0),
+                                       ((64, 16, 20, 128, 128, 4), 1), ((8, 4, 4, 32, 32, 4), 1), ((6, 5, 3, 24, 24, 4), 1),
                                        ((4, 3, 2, 16, 16, 2), 0), ((3, 2, 11, 64, 128, 4), 1)])
 def test_planner_covers_geometry(dims, fast):
     """dfx_plan_make is host-only code: runs without a GPU."""
@@ -149,7 +149,8 @@ def test_planner_covers_geometry(dims, fast):
     assert p.v_part_elems == p.n_zchunks * n_t * n_l * (X // r) * (Y // r)
     assert p.part_elems >= max(p.n_blocks, cabi.EW_MAXBLOCKS) * cabi.NPART
     if fast:
-        assert p.cpb >= 1 and p.n_blocks == -(-(X // 4) * (Y // 64) // 4) * p.n_zchunks * -(-p.n_chunks // p.cpb)
+        wt = -(-(X // 4) * (Y // 4) // 16)          # wave tiles per plane: 16 blocks each
+        assert p.cpb >= 1 and p.n_blocks == -(-wt // 4) * p.n_zchunks * -(-p.n_chunks // p.cpb)
 
 
 def test_planner_rejects_bad_geometry():

@@ -138,7 +138,7 @@ def test_cg_fast_path_vs_oracle(shape):
 
 def test_fast_and_generic_kernels_agree():
     """Same sweep through both kernel families (generic path forced by planning with r = 4 but
-    Y % 64 != 0 is impossible for the same data, so compare u, v, scalars of a projection)."""
+    compare u, v, scalars of a projection with float64 torch)."""
     from datafusion_amd import _cabi as cabi
     from datafusion_amd.kernels import HipKernels
     torch.manual_seed(0)
@@ -234,18 +234,18 @@ def test_sliced_sweep_is_bitwise_identical():
     assert O.rel_l2(out[0][1].cpu(), ref_p.cpu()) <= 1e-6
 
 
-@pytest.mark.parametrize("dims", [(5, 3, 7, 64, 128), (1, 1, 1, 12, 64), (2, 1, 9, 20, 192), (3, 2, 4, 4, 64),
-                                  (70, 3, 5, 8, 64), (2, 2, 3, 12, 20)])
+@pytest.mark.parametrize("dims", [(5, 3, 7, 64, 128, 4), (1, 1, 1, 12, 64, 4), (2, 1, 9, 20, 192, 4), (3, 2, 4, 4, 64, 4),
+                                  (70, 3, 5, 8, 64, 4), (2, 2, 3, 12, 20, 4), (3, 2, 5, 4, 4, 4), (2, 3, 2, 36, 100, 4),
+                                  (2, 2, 3, 12, 20, 2), (3, 1, 2, 16, 24, 8), (2, 2, 2, 9, 15, 3)])
 def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     """Every 5-D kernel against torch float64 formulas on shapes the solver tests cannot reach (X != Y, one wave
-    tile, inactive waves in the last workgroup, fewer slabs than workgroups, ragged z-chunks; last: generic path)."""
+    tile, inactive waves in the last workgroup, fewer slabs than workgroups, ragged z-chunks, block rows that wrap inside a wave, a plane smaller than a wave; r != 4: generic path)."""
     from datafusion_amd import _cabi as cabi
     from datafusion_amd.kernels import HipKernels
     torch.manual_seed(2)
-    n_t, n_l, n_z, X, Y = dims
-    r = 4
+    n_t, n_l, n_z, X, Y, r = dims
     k = HipKernels(n_t, n_l, n_z, X, Y, r, DEV)
-    assert k.plan.fast == (1 if Y % 64 == 0 else 0)
+    assert k.plan.fast == (1 if r == 4 else 0)
     x, rr, p = (torch.randn(k.shape, device=DEV) for _ in range(3))
     al, be = 0.37, -0.61
     k.scal[cabi.S_ALPHA], k.scal[cabi.S_BETA] = al, be
