@@ -66,7 +66,7 @@ struct Geo {
     long long N;   // M*S
     int M;         // nT*nL
     int nZ, X, Y, Xs, Ys, r;
-    int WT;        // wave tiles per plane (fast path): ceil(nblk / 16)
+    int WT;        // wave tiles per plane (fast path): ceil(nblk / BW), BW = 64, 16, 4 blocks per wave for r = 2, 4, 8
     int nblk;      // r x r blocks per plane = Xs*Ys
 };
 
@@ -91,12 +91,16 @@ int make_geo(const dfx_geom *g, Geo *o) {
     o->N = o->S * M;
     if (o->S > 0x7fffffffLL) return fail(DFX_EINVAL, "one (t,l) slab must stay below 2^31 elements");
     o->nblk = o->Xs * o->Ys;
-    o->WT = (o->nblk + 15) / 16;
+    {
+        const int bw = o->r == 2 ? 64 : (o->r == 8 ? 4 : 16);   // LaneMap<R>::BW
+        o->WT = (o->nblk + bw - 1) / bw;
+    }
     return 0;
 }
 
-// r = 4 (then X, Y are multiples of 4: rows are 16-byte aligned and a float4 is one block row)
-bool fast_ok(const Geo &q) { return q.r == 4; }
+// r in {2, 4, 8} with Y a multiple of 4 (implied for r = 4, 8): every plane row is 16-byte aligned and a float4
+// never straddles a block row (r = 4, 8) or covers exactly two blocks (r = 2).  See LaneMap<R>.
+bool fast_ok(const Geo &q) { return (q.r == 2 || q.r == 4 || q.r == 8) && (q.Y % 4) == 0; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -151,6 +155,60 @@ __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); 
 __device__ __forceinline__ float dot4(f4 a, f4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
 // ------------------------------------------------------------------------------------------
+// Lane mapping of the fast kernels, r in {2, 4, 8}.  A lane owns one float4 of a plane; a wave covers R rows of
+// 64/R float4 each, i.e. BW consecutive r x r blocks (row-major over (x/r, y/r)):
+//   r = 2: 2 rows x 32 float4, a float4 spans TWO blocks        -> 64 blocks, partner row in lane ^ 32
+//   r = 4: 4 rows x 16 float4, a float4 is one block row        -> 16 blocks, rows in lanes l, l^16, l^32, l^48
+//   r = 8: 8 rows x  8 float4, two float4 make one block row    ->  4 blocks, halves in l^1, rows in l^8, ^16, ^32
+// All lanes of one block are active together, so the shuffles below never read an idle lane.
+// ------------------------------------------------------------------------------------------
+template <int R>
+struct LaneMap {
+    static constexpr int UPR = 64 / R;                               // float4 units per wave row
+    static constexpr int BW = (R == 2) ? 64 : (R == 4 ? 16 : 4);     // blocks per wave
+    int blk;          // first (r = 2) or only block this lane contributes to
+    bool act;
+    long long off2;   // element offset of the lane's float4 inside a plane
+    __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
+        const int dx = lane / UPR, j = lane % UPR;
+        blk = wt * BW + (R == 2 ? 2 * j : (R == 4 ? j : (j >> 1)));
+        act = blk < q.nblk;
+        const int xb = blk / q.Ys, yb = blk - xb * q.Ys;
+        off2 = (long long)(xb * R + dx) * q.Y + yb * R + (R == 8 ? (j & 1) * 4 : 0);
+    }
+    // s4 = the lane's float4 summed over z; writes the r x r block sums to vrow[block]
+    __device__ __forceinline__ void vstore(f4 s4, float *vrow, int lane) const {
+        if (R == 2) {
+            float s0 = s4.x + s4.y, s1 = s4.z + s4.w;
+            s0 += __shfl_xor(s0, 32);
+            s1 += __shfl_xor(s1, 32);
+            if (lane < 32) *reinterpret_cast<float2 *>(vrow + blk) = make_float2(s0, s1);
+        } else if (R == 4) {
+            float s = hsum(s4);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) vrow[blk] = s;
+        } else {
+            float s = hsum(s4);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 8);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 8 && !(lane & 1)) vrow[blk] = s;
+        }
+    }
+    // the small-space value(s) under the lane's float4, spread over its four elements
+    __device__ __forceinline__ f4 bload(const float *brow) const {
+        if (R == 2) {
+            const float2 b = *reinterpret_cast<const float2 *>(brow + blk);
+            return (f4){b.x, b.x, b.y, b.y};
+        }
+        const float b = brow[blk];
+        return (f4){b, b, b, b};
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // Fast sweep: x += alpha p ; p = r + beta p ; u(p), v(p), ||p||^2, ||x||^2, <x,p>   (MODE XP)
 // ------------------------------------------------------------------------------------------
 struct SweepArgs {
@@ -169,10 +227,11 @@ struct SweepArgs {
     int row0;      // first row of `part` this launch writes
 };
 
-template <int MODE, int ZC, bool FULL>
+template <int MODE, int ZC, int R, bool FULL>
 __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0, int m1, int ms, long long off,
-                                            long long voff, float fa, float fb, f4 (&uacc)[ZC], double &dpp,
+                                            const LaneMap<R> &L, float fa, float fb, f4 (&uacc)[ZC], double &dpp,
                                             double &dxx, double &dxp) {
+    float *vbase = a.v_part + (long long)blockIdx.y * a.q.M * a.q.Ps;
     const int lane = threadIdx.x & 63;
     constexpr int ZB = ZC < DFX_ZB ? ZC : DFX_ZB;
     for (int m = m0; m < m1; m += ms) {
@@ -233,18 +292,14 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
                 }
             }
         }
-        // 4x4 block sum: the lane's float4 is one block row; rows live in lanes l, l^16, l^32, l^48
-        float s = hsum(s4);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (lane < 16) a.v_part[voff + (long long)m * a.q.Ps] = s;
+        L.vstore(s4, vbase + (long long)m * a.q.Ps, lane);
         dpp += (double)pp;
         dxx += (double)xx;
         dxp += (double)xp;
     }
 }
 
-template <int MODE, int ZC>
+template <int MODE, int ZC, int R>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(const SweepArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
@@ -252,15 +307,10 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
     const int zcnt = min(ZC, a.q.nZ - z0);
     const int gz = gridDim.z, bz = blockIdx.z;
     double dpp = 0, dxx = 0, dxp = 0;
-    // a wave owns 16 consecutive 4x4 blocks of the plane (row-major over (x/4, y/4)); lanes l, l^16, l^32, l^48
-    // hold the four rows of block (l & 15).  Only the last wave of a plane can have idle lanes.
-    const int blk = wt * 16 + (lane & 15);
-    if (blk < a.q.nblk) {
-        const int xb = blk / a.q.Ys, yb = blk - xb * a.q.Ys;
-        const int row = xb * 4 + (lane >> 4);
-        const int col = yb * 4;
-        const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
-        const long long voff = (long long)blockIdx.y * a.q.M * a.q.Ps + blk;
+    // a wave owns LaneMap<R>::BW consecutive r x r blocks of the plane; only the last wave can have idle lanes
+    const LaneMap<R> L(a.q, wt, lane);
+    if (L.act) {
+        const long long off = (long long)z0 * a.q.P + L.off2;
         const float fa = (MODE == DFX_SWEEP_XP) ? (float)a.scal[DFX_S_ALPHA] : 0.f;
         const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)a.scal[DFX_S_BETA] : 0.f;
         for (int c = a.c_lo; c < a.c_hi; ++c) {
@@ -275,9 +325,9 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
 #pragma unroll
             for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
             if (zcnt == ZC)
-                sweep_steps<MODE, ZC, true>(a, zcnt, m0, m1, ms, off, voff, fa, fb, uacc, dpp, dxx, dxp);
+                sweep_steps<MODE, ZC, R, true>(a, zcnt, m0, m1, ms, off, L, fa, fb, uacc, dpp, dxx, dxp);
             else
-                sweep_steps<MODE, ZC, false>(a, zcnt, m0, m1, ms, off, voff, fa, fb, uacc, dpp, dxx, dxp);
+                sweep_steps<MODE, ZC, R, false>(a, zcnt, m0, m1, ms, off, L, fa, fb, uacc, dpp, dxx, dxp);
             float *up = a.u_part + (long long)chunk * a.q.S + off;
 #pragma unroll
             for (int k = 0; k < ZC; ++k)
@@ -304,21 +354,21 @@ struct BcastArgs {
     int steps, n_chunks, cpb;
 };
 
-template <int ZC, bool HAS_IN, bool HAS_MASK, bool FULL>
+template <int ZC, int R, bool HAS_IN, bool HAS_MASK, bool FULL>
 __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0, int m1, int ms, long long off,
-                                            long long boff, float cb, const f4 (&av)[ZC], const f4 (&mk)[ZC],
+                                            const LaneMap<R> &L, float cb, const f4 (&av)[ZC], const f4 (&mk)[ZC],
                                             double &drr) {
     // MU slabs per trip: one wave per SIMD is the fastest residency for these kernels, so the loads in
     // flight per lane (MU * ZC float4) are what hides HBM latency
     constexpr int MU = (DFX_BCAST_INFLIGHT / ZC) > 0 ? DFX_BCAST_INFLIGHT / ZC : 1;
     for (int m = m0; m < m1; m += ms * MU) {
-        float b[MU];
+        f4 b[MU];
         f4 iv[MU][ZC];
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
             const int mm = m + u * ms;
             if (mm < m1) {
-                b[u] = cb * a.B[boff + (long long)mm * a.q.Ps];
+                b[u] = cb * L.bload(a.B + (long long)mm * a.q.Ps);
                 if (HAS_IN) {
                     const long long base = (long long)mm * a.q.S + off;
 #pragma unroll
@@ -336,7 +386,7 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0
 #pragma unroll
                 for (int k = 0; k < ZC; ++k) {
                     if (FULL || k < zcnt) {
-                        f4 o = av[k] + (HAS_MASK ? mk[k] * b[u] : (f4){b[u], b[u], b[u], b[u]});
+                        f4 o = av[k] + (HAS_MASK ? mk[k] * b[u] : b[u]);
                         if (HAS_IN) o += iv[u][k];
                         st4s(a.out + base + (long long)k * a.q.P, o);
                         rr += dot4(o, o);
@@ -348,7 +398,7 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0
     }
 }
 
-template <int ZC, bool HAS_IN, bool HAS_MASK>
+template <int ZC, int R, bool HAS_IN, bool HAS_MASK>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(const BcastArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
@@ -356,13 +406,9 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(con
     const int zcnt = min(ZC, a.q.nZ - z0);
     const int m0 = blockIdx.z, ms = gridDim.z, m1 = a.q.M;
     double drr = 0;
-    const int blk = wt * 16 + (lane & 15);
-    if (blk < a.q.nblk) {
-        const int xb = blk / a.q.Ys, yb = blk - xb * a.q.Ys;
-        const int row = xb * 4 + (lane >> 4);
-        const int col = yb * 4;
-        const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
-        const long long boff = blk;
+    const LaneMap<R> L(a.q, wt, lane);
+    if (L.act) {
+        const long long off = (long long)z0 * a.q.P + L.off2;
         const float coef = a.coef_host * (a.coef_dev ? (float)(*a.coef_dev) : 1.f);
         const float ca = coef * a.sa, cb = coef * a.sb;
         f4 av[ZC], mk[ZC];
@@ -379,9 +425,9 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(con
             }
         }
         if (zcnt == ZC)
-            bcast_steps<ZC, HAS_IN, HAS_MASK, true>(a, zcnt, m0, m1, ms, off, boff, cb, av, mk, drr);
+            bcast_steps<ZC, R, HAS_IN, HAS_MASK, true>(a, zcnt, m0, m1, ms, off, L, cb, av, mk, drr);
         else
-            bcast_steps<ZC, HAS_IN, HAS_MASK, false>(a, zcnt, m0, m1, ms, off, boff, cb, av, mk, drr);
+            bcast_steps<ZC, R, HAS_IN, HAS_MASK, false>(a, zcnt, m0, m1, ms, off, L, cb, av, mk, drr);
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     block_store3(drr, 0.0, 0.0, a.part + bid * DFX_NPART);
@@ -428,7 +474,7 @@ __device__ __forceinline__ f4 adam_elem4(f4 x, f4 g, f4 &m1, f4 &m2, const AdamA
     return (f4){x0, x1, x2, x3};
 }
 
-template <int ZC, bool HAS_MASK>
+template <int ZC, int R, bool HAS_MASK>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(const AdamArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
@@ -436,14 +482,10 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
     const int zcnt = min(ZC, a.q.nZ - z0);
     const int gz = gridDim.z, bz = blockIdx.z;
     double ddd = 0, dxx = 0;
-    const int blk = wt * 16 + (lane & 15);
-    if (blk < a.q.nblk) {
-        const int xb = blk / a.q.Ys, yb = blk - xb * a.q.Ys;
-        const int row = xb * 4 + (lane >> 4);
-        const int col = yb * 4;
-        const long long off = (long long)z0 * a.q.P + (long long)row * a.q.Y + col;
-        const long long boff = blk;
-        const long long voff = (long long)blockIdx.y * a.q.M * a.q.Ps + boff;
+    const LaneMap<R> L(a.q, wt, lane);
+    if (L.act) {
+        const long long off = (long long)z0 * a.q.P + L.off2;
+        float *vbase = a.v_part + (long long)blockIdx.y * a.q.M * a.q.Ps;
         f4 av[ZC], mk[ZC];
 #pragma unroll
         for (int k = 0; k < ZC; ++k) {
@@ -462,7 +504,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
             for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
             for (int m = m0; m < m1e; m += gz) {
                 const long long base = (long long)m * a.q.S + off;
-                const float b = a.B[boff + (long long)m * a.q.Ps];
+                const f4 b = L.bload(a.B + (long long)m * a.q.Ps);
                 f4 s4 = {0.f, 0.f, 0.f, 0.f};
                 float dd = 0.f, xx = 0.f;
                 constexpr int ZB = ZC < DFX_ADAM_ZB ? ZC : DFX_ADAM_ZB;   // planes loaded, updated, stored together
@@ -483,7 +525,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
                         const int k = g0 + j;
                         if (k < zcnt) {
                             const long long i = base + (long long)k * a.q.P;
-                            f4 g = av[k] + (f4){b, b, b, b};
+                            f4 g = av[k] + b;
                             if (HAS_MASK) g *= mk[k];
                             const f4 xn = adam_elem4(xv[j], g, e1[j], e2[j], a);
                             st4s(a.x + i, xn);
@@ -497,10 +539,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
                         }
                     }
                 }
-                float sv = hsum(s4);
-                sv += __shfl_xor(sv, 16);
-                sv += __shfl_xor(sv, 32);
-                if (lane < 16) a.v_part[voff + (long long)m * a.q.Ps] = sv;
+                L.vstore(s4, vbase + (long long)m * a.q.Ps, lane);
                 ddd += (double)dd;
                 dxx += (double)xx;
             }
@@ -899,7 +938,7 @@ int check_plan(const Geo &q, const dfx_plan *pl) {
         return fail(DFX_EPLAN, "plan not initialised (call dfx_plan_make)");
     if (pl->fast) {
         if (!fast_ok(q)) return fail(DFX_EPLAN, "fast plan on a geometry that needs the generic path");
-        if (pl->zc != 4 && pl->zc != 8 && pl->zc != 16) return fail(DFX_EPLAN, "fast plan: zc must be 4, 8 or 16");
+        if (pl->zc != 4 && pl->zc != 8) return fail(DFX_EPLAN, "fast plan: zc must be 4 or 8");
         if (pl->cpb <= 0 || pl->n_chunks % pl->cpb) return fail(DFX_EPLAN, "plan: n_chunks must be a multiple of cpb");
         if ((long long)pl->zc * pl->n_zchunks < q.nZ || (long long)pl->steps * pl->n_chunks < q.M)
             return fail(DFX_EPLAN, "plan does not cover the geometry");
@@ -915,15 +954,26 @@ int check_plan(const Geo &q, const dfx_plan *pl) {
 }
 
 bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+bool aligned8(const void *p) { return (((uintptr_t)p) & 7) == 0; }   // small-space rows: float2 access when r = 2
+
+// the fast kernels exist for zc in {4, 8} x r in {2, 4, 8}; check_plan / fast_ok admit nothing else
+#define DFX_DISPATCH_R(ZCV, r, ...)                                        \
+    do {                                                                   \
+        constexpr int ZC_ = ZCV;                                           \
+        if ((r) == 2) { constexpr int R_ = 2; __VA_ARGS__; }               \
+        else if ((r) == 4) { constexpr int R_ = 4; __VA_ARGS__; }          \
+        else { constexpr int R_ = 8; __VA_ARGS__; }                        \
+    } while (0)
+#define DFX_DISPATCH_ZC_R(zc, r, ...)                                      \
+    do {                                                                   \
+        if ((zc) == 4) DFX_DISPATCH_R(4, r, __VA_ARGS__);                  \
+        else DFX_DISPATCH_R(8, r, __VA_ARGS__);                            \
+    } while (0)
 
 template <int MODE>
 int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
     dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
-    switch (pl->zc) {
-        case 4: hipLaunchKernelGGL((k_sweep_fast<MODE, 4>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_sweep_fast<MODE, 8>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((k_sweep_fast<MODE, 16>), grid, block, 0, st, a); break;
-    }
+    DFX_DISPATCH_ZC_R(pl->zc, a.q.r, hipLaunchKernelGGL((k_sweep_fast<MODE, ZC_, R_>), grid, block, 0, st, a));
     DFX_LAUNCH_CHECK("dfx_sweep(fast)");
     return 0;
 }
@@ -931,11 +981,7 @@ int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
 template <bool HAS_IN, bool HAS_MASK>
 int launch_bcast_fast(const BcastArgs &a, const dfx_plan *pl, hipStream_t st) {
     dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
-    switch (pl->zc) {
-        case 4: hipLaunchKernelGGL((k_bcast_fast<4, HAS_IN, HAS_MASK>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_bcast_fast<8, HAS_IN, HAS_MASK>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((k_bcast_fast<16, HAS_IN, HAS_MASK>), grid, block, 0, st, a); break;
-    }
+    DFX_DISPATCH_ZC_R(pl->zc, a.q.r, hipLaunchKernelGGL((k_bcast_fast<ZC_, R_, HAS_IN, HAS_MASK>), grid, block, 0, st, a));
     DFX_LAUNCH_CHECK("dfx_bcast(fast)");
     return 0;
 }
@@ -969,12 +1015,12 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         out->fast = 1;
         int zc;
         // measured on MI355X at t256 x l16 x z16 x 128^2 (tools/tune_kernels.py): zc = 8 beats 16 (which
-        // needs 256 VGPRs + AGPRs) by 5 % and 4 by 3 %; 16 stays available through dfx_plan_make_ex
+        // needs 256 VGPRs + AGPRs, and spills in the Adam kernel) by 5 % and 4 by 3 %: 16 is not built
         if (q.nZ % 8 == 0) zc = 8;
         else if (q.nZ % 4 == 0 || q.nZ < 8) zc = 4;
         else zc = 8;
         if (zc_req) {
-            if (zc_req != 4 && zc_req != 8 && zc_req != 16) return fail(DFX_EINVAL, "zc must be 0 (auto), 4, 8 or 16");
+            if (zc_req != 4 && zc_req != 8) return fail(DFX_EINVAL, "zc must be 0 (auto), 4 or 8");
             zc = zc_req;
         }
         out->zc = zc;
@@ -1057,6 +1103,7 @@ int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float 
     if (pl->fast) {
         if (!aligned16(x) || !aligned16(r) || !aligned16(p) || !aligned16(u_part))
             return fail(DFX_EALIGN, "dfx_sweep: x, r, p, u_part must be 16-byte aligned");
+        if (!aligned8(v_part)) return fail(DFX_EALIGN, "dfx_sweep: v_part must be 8-byte aligned");
         SweepArgs a{x, r, p, scal, u_part, v_part, part, q, pl->steps, pl->n_chunks, pl->cpb, c_lo, c_hi,
                     slice * pl->n_blocks};
         int rc;
@@ -1110,6 +1157,7 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
     if (pl->fast) {
         if (!aligned16(out) || !aligned16(in) || !aligned16(A) || !aligned16(mask))
             return fail(DFX_EALIGN, "dfx_bcast: out, in, A, mask must be 16-byte aligned");
+        if (!aligned8(B)) return fail(DFX_EALIGN, "dfx_bcast: B must be 8-byte aligned");
         int rc;
         if (in)
             rc = mask ? launch_bcast_fast<true, true>(a, pl, st) : launch_bcast_fast<true, false>(a, pl, st);
@@ -1146,19 +1194,11 @@ int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, fl
             return fail(DFX_EALIGN, "dfx_adam_step: x, m1, m2, A, mask, u_part must be 16-byte aligned");
         dim3 grid((q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb),
             block(64 * DFX_WAVES);
-        if (mask) {
-            switch (pl->zc) {
-                case 4: hipLaunchKernelGGL((k_adam_fast<4, true>), grid, block, 0, st, a); break;
-                case 8: hipLaunchKernelGGL((k_adam_fast<8, true>), grid, block, 0, st, a); break;
-                default: return fail(DFX_EPLAN, "dfx_adam_step: zc must be 4 or 8");
-            }
-        } else {
-            switch (pl->zc) {
-                case 4: hipLaunchKernelGGL((k_adam_fast<4, false>), grid, block, 0, st, a); break;
-                case 8: hipLaunchKernelGGL((k_adam_fast<8, false>), grid, block, 0, st, a); break;
-                default: return fail(DFX_EPLAN, "dfx_adam_step: zc must be 4 or 8 (16 would spill)");
-            }
-        }
+        if (!aligned8(B) || !aligned8(v_part)) return fail(DFX_EALIGN, "dfx_adam_step: B, v_part must be 8-byte aligned");
+        if (mask)
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, true>), grid, block, 0, st, a));
+        else
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false>), grid, block, 0, st, a));
         DFX_LAUNCH_CHECK("dfx_adam_step(fast)");
         n_rows = pl->n_blocks;
     } else {

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 105
+#define DFX_VERSION 106
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -38,7 +38,7 @@ typedef struct dfx_geom {
 } dfx_geom;
 
 /* Launch plan + workspace sizes for one geometry.  fast=1: float4 wave-tile kernels
- * (r == 4); fast=0: shape-generic kernels (any r). */
+ * (r in {2, 4, 8} and Y % 4 == 0; small-space rows B / v_part 8-byte aligned); fast=0: shape-generic kernels (any r). */
 typedef struct dfx_plan {
     int32_t fast;
     int32_t zc;          /* z planes a workgroup keeps in registers */
@@ -91,7 +91,7 @@ const char *dfx_last_error(void);
 /* Choose the launch plan and workspace sizes.  target_blocks <= 0 -> default (one workgroup per CU of the
  * current device; 256 when no device is visible). */
 int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out);
-/* Same with overrides for tuning: zc in {0 = auto, 4, 8, 16}, steps (0 = auto). */
+/* Same with overrides for tuning: zc in {0 = auto, 4, 8}, steps (0 = auto). */
 int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc, int32_t steps, dfx_plan *out);
 
 /* One pass over the 5-D vectors (replaces, fused: T,S,D,R forward of fusion.py:44-51,89-98 as

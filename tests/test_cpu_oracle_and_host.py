@@ -114,7 +114,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libdfx.so does not export {n}"
-    assert cabi.lib().dfx_version() == 105
+    assert cabi.lib().dfx_version() == 106
 
 
 def test_header_constants_match_python_mirror():
@@ -132,7 +132,9 @@ def test_header_constants_match_python_mirror():
 
 @pytest.mark.parametrize("dims,fast", [((256, 16, 16, 128, 128, 4), 1), ((512, 32, 4, 256, 256, 4), 1),
                                        ((64, 16, 20, 128, 128, 4), 1), ((8, 4, 4, 32, 32, 4), 1), ((6, 5, 3, 24, 24, 4), 1),
-                                       ((4, 3, 2, 16, 16, 2), 0), ((3, 2, 11, 64, 128, 4), 1)])
+                                       ((4, 3, 2, 16, 16, 2), 1), ((3, 2, 11, 64, 128, 4), 1), ((4, 2, 3, 32, 32, 8), 1),
+                                       ((2, 2, 2, 10, 6, 2), 0), ((2, 2, 2, 9, 15, 3), 0), ((7, 3, 5, 6, 132, 2), 1),
+                                       ((2, 3, 9, 24, 40, 8), 1)])
 def test_planner_covers_geometry(dims, fast):
     """dfx_plan_make is host-only code: runs without a GPU."""
     from datafusion_amd import _cabi as cabi
@@ -149,7 +151,7 @@ def test_planner_covers_geometry(dims, fast):
     assert p.v_part_elems == p.n_zchunks * n_t * n_l * (X // r) * (Y // r)
     assert p.part_elems >= max(p.n_blocks, cabi.EW_MAXBLOCKS) * cabi.NPART
     if fast:
-        wt = -(-(X // 4) * (Y // 4) // 16)          # wave tiles per plane: 16 blocks each
+        wt = -(-(X // r) * (Y // r) // {2: 64, 4: 16, 8: 4}[r])          # wave tiles per plane: 64 / 16 / 4 blocks each
         assert p.cpb >= 1 and p.n_blocks == -(-wt // 4) * p.n_zchunks * -(-p.n_chunks // p.cpb)
 
 

@@ -236,16 +236,19 @@ def test_sliced_sweep_is_bitwise_identical():
 
 @pytest.mark.parametrize("dims", [(5, 3, 7, 64, 128, 4), (1, 1, 1, 12, 64, 4), (2, 1, 9, 20, 192, 4), (3, 2, 4, 4, 64, 4),
                                   (70, 3, 5, 8, 64, 4), (2, 2, 3, 12, 20, 4), (3, 2, 5, 4, 4, 4), (2, 3, 2, 36, 100, 4),
-                                  (2, 2, 3, 12, 20, 2), (3, 1, 2, 16, 24, 8), (2, 2, 2, 9, 15, 3)])
+                                  (2, 2, 3, 12, 20, 2), (3, 1, 2, 16, 24, 8), (2, 2, 2, 9, 15, 3), (2, 2, 2, 10, 6, 2),
+                                  (7, 3, 5, 6, 132, 2), (2, 3, 9, 24, 40, 8), (5, 3, 7, 64, 128, 2), (5, 3, 7, 64, 128, 8),
+                                  (70, 2, 4, 2, 4, 2), (3, 2, 3, 8, 8, 8)])
 def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     """Every 5-D kernel against torch float64 formulas on shapes the solver tests cannot reach (X != Y, one wave
-    tile, inactive waves in the last workgroup, fewer slabs than workgroups, ragged z-chunks, block rows that wrap inside a wave, a plane smaller than a wave; r != 4: generic path)."""
+    tile, inactive waves in the last workgroup, fewer slabs than workgroups, ragged z-chunks, block rows that wrap inside
+    a wave, a plane smaller than a wave; r = 2, 4, 8 with Y % 4 == 0 take the fast kernels, everything else the generic)."""
     from datafusion_amd import _cabi as cabi
     from datafusion_amd.kernels import HipKernels
     torch.manual_seed(2)
     n_t, n_l, n_z, X, Y, r = dims
     k = HipKernels(n_t, n_l, n_z, X, Y, r, DEV)
-    assert k.plan.fast == (1 if r == 4 else 0)
+    assert k.plan.fast == (1 if r in (2, 4, 8) and Y % 4 == 0 else 0)
     x, rr, p = (torch.randn(k.shape, device=DEV) for _ in range(3))
     al, be = 0.37, -0.61
     k.scal[cabi.S_ALPHA], k.scal[cabi.S_BETA] = al, be

@@ -2,7 +2,7 @@
 build variants (DFX_LIB=<variant .so>) and plan overrides.  Interleaved rounds in one process per
 library; prints one line per configuration.
 
-    DFX_LIB=build/libdfx_nt1_mw1.so python tools/tune_kernels.py --zc 16,8,4 --steps 32,64
+    DFX_LIB=build/libdfx_nt1_mw1.so python tools/tune_kernels.py --zc 8,4 --steps 32,64
 """
 import argparse
 import os
