@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--method", default="cg", choices=["cg", "adam", "adam-autograd"],
                     help="cg (the headline metric) | adam: fused dfx_adam_step | adam-autograd: autograd.Function + torch Adam")
     ap.add_argument("--no-defer", action="store_true", help="textbook ordering (x updated with r): 8N words/iter")
+    ap.add_argument("--residual", default="factored", choices=["factored", "explicit"],
+                    help="factored (default): r kept as its two small-space factors, 4N words/iter | explicit: r is a "
+                         "third 5-D vector, 7N words/iter")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--target-blocks", type=int, default=0)
     a = ap.parse_args()
@@ -152,7 +155,7 @@ def main():
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
     f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
                  mask_noise=False, total_energy=1, device=dev, seed=42, group=group, defer_x=not a.no_defer,
-                 target_blocks=a.target_blocks)
+                 target_blocks=a.target_blocks, residual=a.residual)
     n_local = f.k.N
     n_total = n_local * world
 
@@ -180,9 +183,14 @@ def main():
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
     # per-iteration time of each entry point (a z-sharded sweep is cut into several launches: sum them)
     kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in timing.items()}
-    sweep_name = "sweep2" if a.no_defer else "sweep1"
+    fact = a.residual == "factored"
+    sweep_name = ("sweep2" if a.no_defer else "sweep1") + ("f" if fact else "")
     sweep_ms = kern[sweep_name]
-    sweep_bytes = (3 if a.no_defer else 5) * 4 * n_local          # words the kernel must move
+    # words the sweep must move: x, p read + written (deferred x update) or p read + written, plus the
+    # read of r when it is an explicit 5-D vector
+    sweep_words = (2 if a.no_defer else 4) + (0 if fact else 1)
+    sweep_bytes = sweep_words * 4 * n_local
+    iter_words = sweep_words + (3 if a.no_defer else 0) + (0 if fact else 2)   # + dfx_axpy, + dfx_bcast
     ach = sweep_bytes / (sweep_ms * 1e-3) / 1e9
     its = a.steps / dt
     # HBM bytes per launch from the committed PMC passes of this same command (profiles/): counters cannot be
@@ -191,7 +199,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if pmc["workload"] == a.workload and world == 1 and not a.no_defer:
-            traffic = pmc["kernels"][f"k_sweep_fast<1, {f.k.plan.zc}>"]["traffic_bytes"]
+            traffic = pmc["kernels"][f"k_sweep_fast<XP,{f.k.plan.zc},r{r},{a.residual}>"]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     out = {
@@ -207,14 +215,18 @@ def main():
                    "value_definition": "CG iterations/s x z-shards (slab-iterations/s): equals iterations/s of the "
                                        "configs[1] volume at 1 GPU; iters_per_s is the iteration rate of the whole "
                                        "sharded volume", "x_update": "textbook" if a.no_defer else "deferred",
+                   "residual": a.residual, "words_moved_per_iteration": f"{iter_words} N",
                    "sweep_launches_per_iteration": len(timing[sweep_name]) // a.steps,
                    "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "cpb", "n_blocks")}},
-        # whole iteration, all GPUs: SURVEY 8(d) prices an iteration at 32 N bytes; this build moves 28 N
+        # whole iteration, all GPUs: SURVEY 8(d) prices an iteration at 32 N bytes and asks for that basis to be quoted
+        # as "effective"; the build moves fewer (16 N with the factored residual), so "effective" may exceed the peak:
+        # the honest bandwidth figure is hbm_moved_GBps and the per-kernel roofline below
         "hbm_effective_GBps": 32.0 * n_total * its / 1e9,
         "hbm_effective_frac_of_peak": 32.0 * n_local * its / 1e9 / HBM_PEAK_GBPS,
-        "hbm_moved_GBps": (32.0 if a.no_defer else 28.0) * n_total * its / 1e9,
+        "hbm_moved_GBps": 4.0 * iter_words * n_total * its / 1e9,
         "kernel_ms": kern,
-        "roofline": {"bound": "hbm", "kernel": f"k_sweep_fast<{'P' if a.no_defer else 'XP'},{f.k.plan.zc}>",
+        "roofline": {"bound": "hbm",
+                     "kernel": f"k_sweep_fast<{'P' if a.no_defer else 'XP'},{f.k.plan.zc},r{r},{a.residual}>",
                      "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                      "traffic": traffic, "bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms},
     }

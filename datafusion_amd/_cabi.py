@@ -26,7 +26,7 @@ class Plan(C.Structure):
 
 # slots of the device state `scal` (include/dfx.h)
 S_RSOLD, S_RSNEW, S_PAP, S_ALPHA, S_BETA, S_TOL, S_UU, S_PP, S_XX, S_XP, S_VV, S_RR, S_XXNEW, S_NONFINITE, \
-    S_ITER, S_SUM, S_SCALE, S_LOSS1, S_LOSS2, S_ADAM_DD, S_ADAM_XX = range(21)
+    S_ITER, S_SUM, S_SCALE, S_LOSS1, S_LOSS2, S_ADAM_DD, S_ADAM_XX, S_RA2, S_RB2, S_RAB = range(24)
 NSCAL = 32
 NPART = 4
 EW_MAXBLOCKS = 2048
@@ -50,6 +50,8 @@ SIGNATURES = {
     "dfx_reduce_u": [_G, _PL, _P, _P, _P, _P, _P],
     "dfx_reduce_v": [_G, _PL, _P, _P, _i64, _i64, _P],
     "dfx_sweep_chunks": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P],
+    "dfx_sweep_factored": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P],
+    "dfx_resid_update": [_G, _P, _P, _P, _P, _f, _f, _f, _P, _i32, _P, _P, _P, _P],
     "dfx_sqnorm": [_P, _i64, _P, _i32, _P, _P],
     "dfx_sqdiff": [_P, _P, _P, _i64, _i64, _d, _P, _i32, _P, _P],
     "dfx_cg_alpha": [_P, _d, _d, _d, _P],

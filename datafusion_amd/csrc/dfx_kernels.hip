@@ -213,7 +213,9 @@ struct LaneMap {
 // ------------------------------------------------------------------------------------------
 struct SweepArgs {
     float *x;
-    const float *r;
+    const float *r;    // explicit residual, or NULL when it is given in factored form:
+    const float *ra;   //   r[t,l,z,x,y] = ra[z,x,y] + rb[t,l,x/r,y/r]   (FACT kernels; never read from a 5-D array)
+    const float *rb;
     float *p;
     const double *scal;
     float *u_part;
@@ -227,10 +229,10 @@ struct SweepArgs {
     int row0;      // first row of `part` this launch writes
 };
 
-template <int MODE, int ZC, int R, bool FULL>
+template <int MODE, int ZC, int R, bool FACT, bool FULL>
 __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0, int m1, int ms, long long off,
-                                            const LaneMap<R> &L, float fa, float fb, f4 (&uacc)[ZC], double &dpp,
-                                            double &dxx, double &dxp) {
+                                            const LaneMap<R> &L, float fa, float fb, const f4 (&rav)[ZC],
+                                            f4 (&uacc)[ZC], double &dpp, double &dxx, double &dxp) {
     float *vbase = a.v_part + (long long)blockIdx.y * a.q.M * a.q.Ps;
     const int lane = threadIdx.x & 63;
     constexpr int ZB = ZC < DFX_ZB ? ZC : DFX_ZB;
@@ -238,6 +240,8 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
         const long long base = (long long)m * a.q.S + off;
         f4 s4 = {0.f, 0.f, 0.f, 0.f};
         float pp = 0.f, xx = 0.f, xp = 0.f;
+        f4 rb4 = {0.f, 0.f, 0.f, 0.f};
+        if (FACT) rb4 = L.bload(a.rb + (long long)m * a.q.Ps);
 #pragma unroll
         for (int g = 0; g < ZC; g += ZB) {
             f4 xv[ZB], rv[ZB], pv[ZB];
@@ -249,14 +253,14 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
                         xv[j] = ld4s(a.x + i);
                     } else if (MODE == DFX_SWEEP_XP) {
                         xv[j] = ld4s(a.x + i);
-                        rv[j] = ld4s(a.r + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
                         pv[j] = ld4s(a.p + i);
                     } else if (MODE == DFX_SWEEP_P) {
-                        rv[j] = ld4s(a.r + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
                         pv[j] = ld4s(a.p + i);
                     } else {  // PINIT
                         xv[j] = ld4s(a.x + i);
-                        rv[j] = ld4s(a.r + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
                     }
                 }
             }
@@ -299,7 +303,7 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
     }
 }
 
-template <int MODE, int ZC, int R>
+template <int MODE, int ZC, int R, bool FACT>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(const SweepArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
@@ -313,6 +317,12 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
         const long long off = (long long)z0 * a.q.P + L.off2;
         const float fa = (MODE == DFX_SWEEP_XP) ? (float)a.scal[DFX_S_ALPHA] : 0.f;
         const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)a.scal[DFX_S_BETA] : 0.f;
+        f4 rav[ZC];   // this lane's piece of the (z, x, y) factor of r: stays in registers for the whole launch
+#pragma unroll
+        for (int k = 0; k < ZC; ++k) {
+            rav[k] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (FACT && k < zcnt) rav[k] = ld4(a.ra + off + (long long)k * a.q.P);
+        }
         for (int c = a.c_lo; c < a.c_hi; ++c) {
             // the u accumulators are flushed every `steps` slabs: bounds the length of an fp32 running sum
             // concurrently running workgroups take ADJACENT slabs (m = i*gz + bz): the chip streams one
@@ -325,9 +335,9 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
 #pragma unroll
             for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
             if (zcnt == ZC)
-                sweep_steps<MODE, ZC, R, true>(a, zcnt, m0, m1, ms, off, L, fa, fb, uacc, dpp, dxx, dxp);
+                sweep_steps<MODE, ZC, R, FACT, true>(a, zcnt, m0, m1, ms, off, L, fa, fb, rav, uacc, dpp, dxx, dxp);
             else
-                sweep_steps<MODE, ZC, R, false>(a, zcnt, m0, m1, ms, off, L, fa, fb, uacc, dpp, dxx, dxp);
+                sweep_steps<MODE, ZC, R, FACT, false>(a, zcnt, m0, m1, ms, off, L, fa, fb, rav, uacc, dpp, dxx, dxp);
             float *up = a.u_part + (long long)chunk * a.q.S + off;
 #pragma unroll
             for (int k = 0; k < ZC; ++k)
@@ -578,9 +588,21 @@ __global__ __launch_bounds__(256) void k_gen_adam(AdamArgs a) {
 // ------------------------------------------------------------------------------------------
 // Generic (any r, X, Y) kernels: element-wise pass + two projection passes.
 // ------------------------------------------------------------------------------------------
+// residual element i of the generic kernels: explicit array, or the factored form ra[z,x,y] + rb[t,l,x/r,y/r]
+__device__ __forceinline__ float gen_resid(const float *r, const float *ra, const float *rb, const Geo &q,
+                                           long long i) {
+    if (r) return r[i];
+    const long long m = i / q.S;
+    const int j = (int)(i - m * q.S);
+    const int xy = j % (int)q.P;
+    const int xi = xy / q.Y, yi = xy - xi * q.Y;
+    return ra[j] + rb[m * q.Ps + (long long)(xi / q.r) * q.Ys + yi / q.r];
+}
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gen_sweep(float *x, const float *r, float *p, const double *scal,
-                                                   long long n, double *part) {
+__global__ __launch_bounds__(256) void k_gen_sweep(float *x, const float *r, const float *ra, const float *rb,
+                                                   float *p, const double *scal, Geo q, double *part) {
+    const long long n = q.N;
     const float fa = (MODE == DFX_SWEEP_XP) ? (float)scal[DFX_S_ALPHA] : 0.f;
     const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)scal[DFX_S_BETA] : 0.f;
     double dpp = 0, dxx = 0, dxp = 0;
@@ -592,18 +614,18 @@ __global__ __launch_bounds__(256) void k_gen_sweep(float *x, const float *r, flo
         } else if (MODE == DFX_SWEEP_XP) {
             const float pv = p[i];
             const float xn = x[i] + fa * pv;
-            const float pn = r[i] + fb * pv;
+            const float pn = gen_resid(r, ra, rb, q, i) + fb * pv;
             x[i] = xn;
             p[i] = pn;
             dxx += (double)(xn * xn);
             dxp += (double)(xn * pn);
             dpp += (double)(pn * pn);
         } else if (MODE == DFX_SWEEP_P) {
-            const float pn = r[i] + fb * p[i];
+            const float pn = gen_resid(r, ra, rb, q, i) + fb * p[i];
             p[i] = pn;
             dpp += (double)(pn * pn);
         } else {
-            const float xv = x[i], pn = r[i];
+            const float xv = x[i], pn = gen_resid(r, ra, rb, q, i);
             p[i] = pn;
             dxx += (double)(xv * xv);
             dxp += (double)(xv * pn);
@@ -719,6 +741,79 @@ __global__ __launch_bounds__(256) void k_fold(const double *parts, int n_rows, i
         }
         if (threadIdx.x == 0) dst[k] = scale * sh[0];
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Factored residual.  r0 = b - A x0 and every A p are sums of a (z,x,y) array broadcast over (t,l) and a
+// (t,l,x/r,y/r) array broadcast over z and the r x r block (fusion.py:423-430), so the CG residual always has the
+// form r = ra[z,x,y] + rb[t,l,x/r,y/r]: it is kept as those two small arrays and never stored as a 5-D vector.
+//   ||r||^2 = M * sum ra^2 + 2 * sum_{t,l,xb,yb} rb * zab[xb,yb] + nZ r^2 * sum rb^2,   zab = sum_z sum_block ra
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resid_a(float *ra, const float *A, long long n, float sa, float coef_host,
+                                                 const double *coef_dev, int accumulate, double *part) {
+    const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f) * sa;
+    double acc = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = (accumulate ? ra[i] : 0.f) + c * A[i];
+        ra[i] = v;
+        acc += (double)v * (double)v;
+    }
+    block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
+}
+
+__global__ __launch_bounds__(256) void k_resid_zab(const float *ra, float *zab, Geo q) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < q.Ps; j += stride) {
+        const int xb = (int)(j / q.Ys), yb = (int)(j - (long long)xb * q.Ys);
+        double s = 0;
+        for (int z = 0; z < q.nZ; ++z)
+            for (int dx = 0; dx < q.r; ++dx)
+                for (int dy = 0; dy < q.r; ++dy)
+                    s += (double)ra[(long long)z * q.P + (long long)(xb * q.r + dx) * q.Y + yb * q.r + dy];
+        zab[j] = (float)s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, const float *zab, long long n,
+                                                 long long Ps, float sb, float coef_host, const double *coef_dev,
+                                                 int accumulate, double *part) {
+    const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f) * sb;
+    double a2 = 0, ab = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = (accumulate ? rb[i] : 0.f) + c * B[i];
+        rb[i] = v;
+        a2 += (double)v * (double)v;
+        ab += (double)v * (double)zab[i % Ps];
+    }
+    block_store3(0.0, a2, ab, part + (long long)blockIdx.x * DFX_NPART);
+}
+
+// RR = M * sum ra^2 + 2 * sum rb zab + nZ r^2 * sum rb^2 from the rows the two kernels above wrote
+__global__ __launch_bounds__(256) void k_resid_rr(const double *parts, int n_rows, double m, double zr2, double *s) {
+    __shared__ double sh[3][256];
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int b = threadIdx.x; b < n_rows; b += 256) {
+        s0 += parts[(long long)b * DFX_NPART + 0];
+        s1 += parts[(long long)b * DFX_NPART + 1];
+        s2 += parts[(long long)b * DFX_NPART + 2];
+    }
+    sh[0][threadIdx.x] = s0;
+    sh[1][threadIdx.x] = s1;
+    sh[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        s[DFX_S_RA2] = sh[0][0];
+        s[DFX_S_RB2] = sh[1][0];
+        s[DFX_S_RAB] = sh[2][0];
+        s[DFX_S_RR] = m * sh[0][0] + 2.0 * sh[2][0] + zr2 * sh[1][0];
     }
 }
 
@@ -973,7 +1068,10 @@ bool aligned8(const void *p) { return (((uintptr_t)p) & 7) == 0; }   // small-sp
 template <int MODE>
 int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
     dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
-    DFX_DISPATCH_ZC_R(pl->zc, a.q.r, hipLaunchKernelGGL((k_sweep_fast<MODE, ZC_, R_>), grid, block, 0, st, a));
+    if (MODE != DFX_SWEEP_PROJECT && a.ra)
+        DFX_DISPATCH_ZC_R(pl->zc, a.q.r, hipLaunchKernelGGL((k_sweep_fast<MODE, ZC_, R_, MODE != DFX_SWEEP_PROJECT>), grid, block, 0, st, a));
+    else
+        DFX_DISPATCH_ZC_R(pl->zc, a.q.r, hipLaunchKernelGGL((k_sweep_fast<MODE, ZC_, R_, false>), grid, block, 0, st, a));
     DFX_LAUNCH_CHECK("dfx_sweep(fast)");
     return 0;
 }
@@ -1085,9 +1183,9 @@ int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, con
     return dfx_sweep_chunks(mode, g, pl, x, r, p, scal, u_part, v_part, part, 0, pl->cpb, 0, 1, stream);
 }
 
-int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
-                     double *scal, float *u_part, float *v_part, double *part, int32_t c_lo, int32_t c_hi,
-                     int32_t slice, int32_t last, void *stream) {
+static int sweep_impl(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, const float *ra,
+                      const float *rb, float *p, double *scal, float *u_part, float *v_part, double *part,
+                      int32_t c_lo, int32_t c_hi, int32_t slice, int32_t last, void *stream) {
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
@@ -1097,14 +1195,17 @@ int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float 
         return fail(DFX_EINVAL, "dfx_sweep_chunks: the generic path sweeps whole volumes only");
     if (mode < DFX_SWEEP_PROJECT || mode > DFX_SWEEP_PINIT) return fail(DFX_EINVAL, "dfx_sweep: bad mode");
     if (!x || !scal || !u_part || !v_part || !part) return fail(DFX_EINVAL, "dfx_sweep: NULL buffer");
-    if (mode != DFX_SWEEP_PROJECT && (!r || !p)) return fail(DFX_EINVAL, "dfx_sweep: r and p required");
+    if (mode != DFX_SWEEP_PROJECT && (!p || !(r || (ra && rb))))
+        return fail(DFX_EINVAL, "dfx_sweep: p and r (or its factors ra, rb) required");
+    if (r) ra = rb = nullptr;
     hipStream_t st = (hipStream_t)stream;
     int n_rows;
     if (pl->fast) {
         if (!aligned16(x) || !aligned16(r) || !aligned16(p) || !aligned16(u_part))
             return fail(DFX_EALIGN, "dfx_sweep: x, r, p, u_part must be 16-byte aligned");
-        if (!aligned8(v_part)) return fail(DFX_EALIGN, "dfx_sweep: v_part must be 8-byte aligned");
-        SweepArgs a{x, r, p, scal, u_part, v_part, part, q, pl->steps, pl->n_chunks, pl->cpb, c_lo, c_hi,
+        if (!aligned8(v_part) || !aligned16(ra) || !aligned8(rb))
+            return fail(DFX_EALIGN, "dfx_sweep: v_part, rb must be 8-byte, ra 16-byte aligned");
+        SweepArgs a{x, r, ra, rb, p, scal, u_part, v_part, part, q, pl->steps, pl->n_chunks, pl->cpb, c_lo, c_hi,
                     slice * pl->n_blocks};
         int rc;
         switch (mode) {
@@ -1119,16 +1220,16 @@ int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float 
         const int nb = pl->n_blocks;
         switch (mode) {
             case DFX_SWEEP_PROJECT:
-                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_PROJECT>, dim3(nb), dim3(256), 0, st, x, r, p, scal, q.N, part);
+                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_PROJECT>, dim3(nb), dim3(256), 0, st, x, r, ra, rb, p, scal, q, part);
                 break;
             case DFX_SWEEP_XP:
-                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_XP>, dim3(nb), dim3(256), 0, st, x, r, p, scal, q.N, part);
+                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_XP>, dim3(nb), dim3(256), 0, st, x, r, ra, rb, p, scal, q, part);
                 break;
             case DFX_SWEEP_P:
-                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_P>, dim3(nb), dim3(256), 0, st, x, r, p, scal, q.N, part);
+                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_P>, dim3(nb), dim3(256), 0, st, x, r, ra, rb, p, scal, q, part);
                 break;
             default:
-                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_PINIT>, dim3(nb), dim3(256), 0, st, x, r, p, scal, q.N, part);
+                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_PINIT>, dim3(nb), dim3(256), 0, st, x, r, ra, rb, p, scal, q, part);
                 break;
         }
         DFX_LAUNCH_CHECK("dfx_sweep(generic)");
@@ -1142,6 +1243,46 @@ int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float 
     // (pp, xx, xp) -> scal[PP], scal[XX], scal[XP] (consecutive slots), over the rows of every slice so far
     if (!last) return 0;
     return fold(part, n_rows, 3, scal + DFX_S_PP, 1.0, st);
+}
+
+int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
+                     double *scal, float *u_part, float *v_part, double *part, int32_t c_lo, int32_t c_hi,
+                     int32_t slice, int32_t last, void *stream) {
+    if (mode != DFX_SWEEP_PROJECT && !r) return fail(DFX_EINVAL, "dfx_sweep: r and p required");
+    return sweep_impl(mode, g, pl, x, r, nullptr, nullptr, p, scal, u_part, v_part, part, c_lo, c_hi, slice, last,
+                      stream);
+}
+
+int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *ra,
+                       const float *rb, float *p, double *scal, float *u_part, float *v_part, double *part,
+                       int32_t c_lo, int32_t c_hi, int32_t slice, int32_t last, void *stream) {
+    if (mode == DFX_SWEEP_PROJECT || !ra || !rb)
+        return fail(DFX_EINVAL, "dfx_sweep_factored: modes XP, P, PINIT with both factors ra, rb");
+    return sweep_impl(mode, g, pl, x, nullptr, ra, rb, p, scal, u_part, v_part, part, c_lo, c_hi, slice, last,
+                      stream);
+}
+
+int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
+                     float coef_host, const double *coef_dev, int32_t accumulate, float *zab, double *scal,
+                     double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (!ra || !rb || !A || !B || !zab || !scal || !part) return fail(DFX_EINVAL, "dfx_resid_update: NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nb_total = (long long)q.M * q.Ps;
+    const int nba = ew_blocks(q.S, 4) > DFX_EW_MAXBLOCKS / 2 ? DFX_EW_MAXBLOCKS / 2 : ew_blocks(q.S, 4);
+    const int nbb = ew_blocks(nb_total, 4) > DFX_EW_MAXBLOCKS / 2 ? DFX_EW_MAXBLOCKS / 2 : ew_blocks(nb_total, 4);
+    hipLaunchKernelGGL(k_resid_a, dim3(nba), dim3(256), 0, st, ra, A, q.S, sa, coef_host, coef_dev, accumulate, part);
+    DFX_LAUNCH_CHECK("dfx_resid_update(a)");
+    hipLaunchKernelGGL(k_resid_zab, dim3(ew_blocks(q.Ps, 1)), dim3(256), 0, st, (const float *)ra, zab, q);
+    DFX_LAUNCH_CHECK("dfx_resid_update(zab)");
+    hipLaunchKernelGGL(k_resid_b, dim3(nbb), dim3(256), 0, st, rb, B, (const float *)zab, nb_total, q.Ps, sb,
+                       coef_host, coef_dev, accumulate, part + (long long)nba * DFX_NPART);
+    DFX_LAUNCH_CHECK("dfx_resid_update(b)");
+    hipLaunchKernelGGL(k_resid_rr, dim3(1), dim3(256), 0, st, (const double *)part, nba + nbb, (double)q.M,
+                       (double)q.nZ * q.r * q.r, scal);
+    DFX_LAUNCH_CHECK("dfx_resid_update(rr)");
+    return 0;
 }
 
 int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in, const float *A,

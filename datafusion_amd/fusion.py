@@ -232,8 +232,15 @@ class Fusion:
 class FusionCG(Fusion):
     """Conjugate gradient on the normal equations (fusion.py:389-496)."""
 
-    def __init__(self, *args, comm_slices: int = 4, **kwargs):
+    def __init__(self, *args, comm_slices: int = 4, residual: str = "factored", **kwargs):
+        """residual="factored" (default): r = b - A x is kept as the two small arrays it is made of,
+        r = ra[z,x,y] + rb[t,l,x/r,y/r] (include/dfx.h, dfx_resid_update) - one 4N-word pass per iteration and
+        two resident 5-D vectors (x, p).  residual="explicit": r is a third 5-D vector updated by dfx_bcast
+        (2N words) and read by the sweep (5N words), the literal transcription of fusion.py:446."""
         super().__init__(*args, **kwargs)
+        if residual not in ("factored", "explicit"):
+            raise ValueError("residual must be 'factored' or 'explicit'")
+        self.residual = residual
         self.w1 = self.weights["spatial"]
         self.w2 = self.weights["spectro_temporal"]
         self._r = self._p = None
@@ -246,13 +253,14 @@ class FusionCG(Fusion):
         the slab axis and the all-reduce of each finished band of v (the RD partials, the one real exchange,
         SURVEY 8e) is started on RCCL's stream while the next band is still being swept."""
         k, c = self.k, self.comm
+        fact = self.residual == "factored"
         if c.size > 1 or c._always:
             pending = []
             k.sweep(mode, self.x, self._r, self._p, slices=self.comm_slices,
-                    after_slice=lambda rows: pending.append(c.sum_async(rows)))
+                    after_slice=lambda rows: pending.append(c.sum_async(rows)), factored=fact)
             c.wait(pending)
         else:
-            k.sweep(mode, self.x, self._r, self._p)
+            k.sweep(mode, self.x, self._r, self._p, factored=fact)
 
     def _finish_projection(self) -> None:
         """After _sweep (v already summed over shards): ||v||^2 and the scalar partials."""
@@ -271,14 +279,22 @@ class FusionCG(Fusion):
         """r0 = b - A(x0), p0 = r0, rsold (fusion.py:428-437), from the current self.x."""
         k, c = self.k, self.comm
         c1, c2 = self._coefs()
-        if self._r is None:
-            self._r, self._p = k.new_vector(), k.new_vector()
+        fact = self.residual == "factored"
+        if self._p is None:
+            self._p = k.new_vector()
+            if fact:
+                k.new_factored_residual()
+            else:
+                self._r = k.new_vector()
         x, rv, pv = self.x, self._r, self._p
         # r0 = c1 bcast(cmos_n - u(x0)) + c2 bcast(spc_n - v(x0))
         self._project(x)
         du = self._cmos_loc - k.u
         dv = self.spc - k.v
-        k.bcast(rv, None, du, dv, None, c1, c2, 1.0, None)
+        if fact:
+            k.resid_update(du, dv, c1, c2, 1.0, None, False)
+        else:
+            k.bcast(rv, None, du, dv, None, c1, c2, 1.0, None)
         c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
         k.cg_start()                                                            # rsold (fusion.py:437)
         self._sweep(cabi.SWEEP_PINIT)                                           # p = r (fusion.py:436)
@@ -304,7 +320,10 @@ class FusionCG(Fusion):
                 c.sum_(k.scal[cabi.S_XXNEW:cabi.S_XXNEW + 1])
             else:
                 self._pending_x = True
-            k.bcast(rv, rv, k.u, k.v, None, c1, c2, -1.0, cabi.S_ALPHA)         # fusion.py:446-447
+            if self.residual == "factored":                                     # fusion.py:446-447
+                k.resid_update(k.u, k.v, c1, c2, -1.0, cabi.S_ALPHA, True)
+            else:
+                k.bcast(rv, rv, k.u, k.v, None, c1, c2, -1.0, cabi.S_ALPHA)
             c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
             k.cg_beta(eps, deferred)                                            # rsnew, tol, beta
             if self.tol is not None or self.verbose:

@@ -56,6 +56,7 @@ class HipKernels:
         self._v_own = (torch.empty((n_t, n_l, self.Xs, self.Ys), dtype=torch.float32, device=dev)
                        if self.plan.n_zchunks > 1 else None)
         self.v = self._v_own if self._v_own is not None else self.v_part.view(n_t, n_l, self.Xs, self.Ys)
+        self.ra = self.rb = self.zab = None   # factored residual (new_factored_residual)
         self.timing = None   # bench.py sets a dict: name -> list of (start, end) torch.cuda.Event pairs
 
     # -- helpers --------------------------------------------------------------------------
@@ -82,6 +83,15 @@ class HipKernels:
     def new_vector(self) -> torch.Tensor:
         return torch.empty(self.shape, dtype=torch.float32, device=self.device)
 
+    def new_factored_residual(self) -> None:
+        """Allocate the two factors of the CG residual, r = ra[z,x,y] + rb[t,l,x/r,y/r] (include/dfx.h), and the
+        Xs*Ys workspace of dfx_resid_update."""
+        if self.ra is None:
+            n_t, n_l, n_z, X, Y = self.shape
+            self.ra = torch.empty((n_z, X, Y), dtype=torch.float32, device=self.device)
+            self.rb = torch.empty((n_t, n_l, self.Xs, self.Ys), dtype=torch.float32, device=self.device)
+            self.zab = torch.empty((self.Xs, self.Ys), dtype=torch.float32, device=self.device)
+
     def _chk(self, *ts):
         for t in ts:
             if t is not None:
@@ -89,8 +99,9 @@ class HipKernels:
 
     # -- 5-D passes -----------------------------------------------------------------------
     @_on_device
-    def sweep(self, mode: int, x, r=None, p=None, slices: int = 1, after_slice=None) -> None:
+    def sweep(self, mode: int, x, r=None, p=None, slices: int = 1, after_slice=None, factored: bool = False) -> None:
         """u(.) -> self.u (+UU), local v partial -> self.v, PP/XX/XP -> scal.
+        factored=True: r is not a 5-D array but self.ra + self.rb (dfx_sweep_factored); pass r=None.
         slices > 1 cuts the pass along the slab axis into that many launches (fast plans; at most cpb);
         after_slice(v_rows) is called after each one with the rows of self.v (viewed (nT*nL, Xs*Ys)) that
         are final - the hook the z-sharded solver uses to start their all-reduce while the sweep goes on."""
@@ -104,11 +115,20 @@ class HipKernels:
         gz = P.n_chunks // P.cpb
         bounds = [P.cpb * j // k for j in range(k + 1)]
         vrows = self.v.view(self.M, self.Xs * self.Ys)
+        if factored:
+            assert r is None and self.ra is not None and mode != cabi.SWEEP_PROJECT
         for j in range(k):
             c_lo, c_hi = bounds[j], bounds[j + 1]
-            cabi.check(self._timed(f"sweep{mode}", self.lib.dfx_sweep_chunks, mode, g, pl, cabi.ptr(x), cabi.ptr(r),
-                                   cabi.ptr(p), cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part),
-                                   cabi.ptr(self.part), c_lo, c_hi, j, int(j == k - 1), s), "dfx_sweep_chunks")
+            if factored:
+                cabi.check(self._timed(f"sweep{mode}f", self.lib.dfx_sweep_factored, mode, g, pl, cabi.ptr(x),
+                                       cabi.ptr(self.ra), cabi.ptr(self.rb), cabi.ptr(p), cabi.ptr(self.scal),
+                                       cabi.ptr(self.u_part), cabi.ptr(self.v_part), cabi.ptr(self.part), c_lo, c_hi,
+                                       j, int(j == k - 1), s), "dfx_sweep_factored")
+            else:
+                cabi.check(self._timed(f"sweep{mode}", self.lib.dfx_sweep_chunks, mode, g, pl, cabi.ptr(x),
+                                       cabi.ptr(r), cabi.ptr(p), cabi.ptr(self.scal), cabi.ptr(self.u_part),
+                                       cabi.ptr(self.v_part), cabi.ptr(self.part), c_lo, c_hi, j, int(j == k - 1), s),
+                           "dfx_sweep_chunks")
             m_lo, m_hi = min(c_lo * P.steps * gz, self.M), min(c_hi * P.steps * gz, self.M)
             if m_hi <= m_lo:
                 continue
@@ -157,6 +177,18 @@ class HipKernels:
                                cabi.ptr(B), cabi.ptr(mask), sa, sb, coef_host,
                                None if coef_slot is None else self.slot_ptr(coef_slot),
                                cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_bcast")
+
+    @_on_device
+    def resid_update(self, A, B, sa: float, sb: float, coef_host: float, coef_slot: int | None,
+                     accumulate: bool) -> None:
+        """ra (+)= coef*sa*A ; rb (+)= coef*sb*B ; RR = ||ra (+) rb||^2 over the 5-D volume (local z planes)."""
+        self._chk(A, B)
+        assert self.ra is not None and A.numel() == self.S and B.numel() == self.M * self.Xs * self.Ys
+        g, _ = self._g()
+        cabi.check(self._timed("resid", self.lib.dfx_resid_update, g, cabi.ptr(self.ra), cabi.ptr(self.rb), cabi.ptr(A),
+                               cabi.ptr(B), sa, sb, coef_host, None if coef_slot is None else self.slot_ptr(coef_slot),
+                               int(accumulate), cabi.ptr(self.zab), cabi.ptr(self.scal), cabi.ptr(self.part),
+                               self._stream()), "dfx_resid_update")
 
     @_on_device
     def axpy(self, y, x, coef_host: float, coef_slot: int | None) -> None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 106
+#define DFX_VERSION 107
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -71,6 +71,7 @@ enum {
     DFX_S_LOSS1 = 17, DFX_S_LOSS2 = 18, /* dfx_sqdiff outputs by convention           */
     DFX_S_ADAM_DD = 19, /* ||x_new - x_old||^2 of the last dfx_adam_step              */
     DFX_S_ADAM_XX = 20, /* ||x_new||^2 of the last dfx_adam_step                      */
+    DFX_S_RA2 = 21, DFX_S_RB2 = 22, DFX_S_RAB = 23, /* sum ra^2, sum rb^2, sum rb*zab of the last dfx_resid_update */
     DFX_NSCAL = 32
 };
 #define DFX_NPART 4          /* doubles per workgroup row of `part` */
@@ -110,6 +111,24 @@ int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, con
 int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
                      double *scal, float *u_part, float *v_part, double *part, int32_t c_lo, int32_t c_hi,
                      int32_t slice, int32_t last, void *stream);
+
+/* Factored residual.  b - A(x0) and every A(p) of fusion.py:423-430 are a (z,x,y) array broadcast over (t,l) plus a
+ * (t,l,x/r,y/r) array broadcast over z and the r x r block, so the CG residual of fusion.py:435,446 always has the
+ * form r[t,l,z,x,y] = ra[z,x,y] + rb[t,l,x/r,y/r].  Kept as those two small arrays it is never stored or read as a
+ * 5-D vector: `r - Ap*alpha` (fusion.py:446) becomes the small-space update below and the sweep forms r on the fly.
+ *
+ * dfx_resid_update:  ra = (accumulate ? ra : 0) + coef*sa*A[z,x,y] ;  rb = (accumulate ? rb : 0) + coef*sb*B[t,l,xb,yb]
+ *   coef = coef_host * (coef_dev ? *coef_dev : 1);  zab = workspace of Xs*Ys floats (sum_z sum_block ra);
+ *   scal[DFX_S_RR] = ||r||^2 = nT*nL*sum ra^2 + 2*sum rb*zab + nZ*r^2*sum rb^2   (torch.dot(r, r), fusion.py:437,447)
+ *   with nZ = g->nZ, the local planes: partials of z-shards add up when rb is replicated.
+ * dfx_sweep_factored: dfx_sweep_chunks (modes XP, P, PINIT) with r given by its factors: x, p read + written
+ *   (4N words for XP instead of 5N + the 2N of dfx_bcast). */
+int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
+                     float coef_host, const double *coef_dev, int32_t accumulate, float *zab, double *scal,
+                     double *part, void *stream);
+int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *ra,
+                       const float *rb, float *p, double *scal, float *u_part, float *v_part, double *part,
+                       int32_t c_lo, int32_t c_hi, int32_t slice, int32_t last, void *stream);
 
 /* out = (in ? in : 0) + coef * mask * (sa * A[z,x,y] + sb * B[t,l,x/r,y/r]),
  * coef = coef_host * (coef_dev ? *coef_dev : 1); mask (nZ,X,Y) optional (NULL = ones).

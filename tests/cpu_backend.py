@@ -21,7 +21,28 @@ class CpuStandIn:
         self.scal = torch.zeros(cabi.NSCAL, dtype=torch.float64)
         self.u = torch.zeros(n_z_local, X, Y)
         self.v = torch.zeros(n_t, n_l, self.Xs, self.Ys)
+        self.ra = self.rb = self.zab = None
         self.timing = None
+
+    def new_factored_residual(self):
+        if self.ra is None:
+            n_t, n_l, n_z, X, Y = self.shape
+            self.ra, self.rb = torch.zeros(n_z, X, Y), torch.zeros(n_t, n_l, self.Xs, self.Ys)
+            self.zab = torch.zeros(self.Xs, self.Ys)
+
+    def _resid5(self):
+        n_t, n_l, n_z, X, Y = self.shape
+        return self.ra.reshape(1, 1, n_z, X, Y) + \
+            self.rb.repeat_interleave(self.r, 2).repeat_interleave(self.r, 3).unsqueeze(2)
+
+    def resid_update(self, A, B, sa, sb, coef_host, coef_slot, accumulate):
+        c = coef_host * (1.0 if coef_slot is None else float(self.scal[coef_slot]))
+        if not accumulate:
+            self.ra.zero_(), self.rb.zero_()
+        self.ra.add_(A.reshape(self.ra.shape), alpha=c * sa)
+        self.rb.add_(B.reshape(self.rb.shape), alpha=c * sb)
+        self.scal[cabi.S_RR] = (self._resid5().double() ** 2).sum()   # the plain 5-D norm (the HIP side uses the
+                                                                       # small-space identity: cross-checks it)
 
     def new_vector(self):
         return torch.empty(self.shape)
@@ -32,7 +53,10 @@ class CpuStandIn:
         self.v.copy_(a.sum(2).reshape(n_t, n_l, self.Xs, self.r, self.Ys, self.r).sum((3, 5)))
         self.scal[cabi.S_UU] = (self.u.double() ** 2).sum()
 
-    def sweep(self, mode, x, r=None, p=None, slices=1, after_slice=None):
+    def sweep(self, mode, x, r=None, p=None, slices=1, after_slice=None, factored=False):
+        if factored:
+            assert r is None
+            r = self._resid5()
         self._sweep(mode, x, r, p)
         if after_slice is not None:           # hand v over in `slices` bands, like the HIP backend
             rows = self.v.view(self.M, -1)

@@ -25,7 +25,7 @@ def _worker(rank, world, port, case, q):
     kw = dict(weights=w, init_type=case["init"], tol=case["tol"], mask_noise=case["mask"], device="cpu",
               group=dist.group.WORLD, defer_x=case["defer"])
     if case["method"] == "cg":
-        f = FusionCG(spc, cmos, **kw)
+        f = FusionCG(spc, cmos, residual=case.get("residual", "factored"), **kw)
         x, _, _ = f(case["iters"], return_numpy=False)
     else:
         f = FusionAdam(spc, cmos, fused=case.get("fused", True), **kw)
@@ -78,6 +78,10 @@ def test_gloo_cg_deferred_masked():
 
 def test_gloo_cg_textbook_tolerance_break_random_init():
     _check(dict(method="cg", init="random", tol=3e-3, mask=False, defer=False, iters=30), 29612)
+
+
+def test_gloo_cg_explicit_residual():
+    _check(dict(method="cg", init="baseline", tol=None, mask=False, defer=True, iters=8, residual="explicit"), 29615)
 
 
 def test_gloo_adam_fused():

@@ -28,14 +28,15 @@ CG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("residual", ["factored", "explicit"])
 @pytest.mark.parametrize("defer", [True, False])
 @pytest.mark.parametrize("name,iters,kw", CG_CASES)
-def test_cg_matches_reference_goldens(golden, name, iters, kw, defer):
+def test_cg_matches_reference_goldens(golden, name, iters, kw, defer, residual):
     from datafusion_amd import FusionCG
     g = golden(name)
     for k in iters:
         f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV,
-                     defer_x=defer, **kw)
+                     defer_x=defer, residual=residual, **kw)
         assert O.rel_l2(f.x.cpu(), g["x0"]) <= TIGHT
         assert O.rel_l2(f.spc.cpu(), g["spc_n"]) <= 1e-6 and O.rel_l2(f.cmos.cpu(), g["cmos_n"]) <= 1e-6
         assert np.array_equal(f.spc_mask.cpu().numpy(), g["spc_mask"])
@@ -61,8 +62,9 @@ def test_cg_verbose_history_matches_reference(golden):
 def test_cg_tolerance_break_matches_reference(golden):
     from datafusion_amd import FusionCG
     g = golden("cg_tol_t8l4z4_32")
-    for defer in (True, False):
-        f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=3e-3, device=DEV, defer_x=defer)
+    for defer, residual in ((True, "factored"), (False, "factored"), (True, "explicit"), (False, "explicit")):
+        f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=3e-3, device=DEV, defer_x=defer,
+                     residual=residual)
         x, _, _ = f(50)
         assert f.curr_iter == int(g["curr_iter"])
         assert O.rel_l2(x, g["x"]) <= TIGHT
@@ -128,12 +130,13 @@ def test_cg_fast_path_vs_oracle(shape):
     from datafusion_amd import FusionCG
     w = {"spatial": 0.3, "spectro_temporal": 0.7}
     spc, cmos = O.synthetic_inputs(*shape, seed=11)
-    f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV)
-    assert f.k.plan.fast == 1
-    x, _, _ = f(12)
     pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
     xo = O.cg(pb, 12, with_loss=False)
-    assert O.rel_l2(x, xo) <= TIGHT
+    for residual in ("factored", "explicit"):
+        f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV, residual=residual)
+        assert f.k.plan.fast == 1
+        x, _, _ = f(12)
+        assert O.rel_l2(x, xo) <= TIGHT, residual
 
 
 def test_fast_and_generic_kernels_agree():
@@ -275,9 +278,35 @@ def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     p3 = torch.full_like(p, float("nan"))
     k.sweep(cabi.SWEEP_PINIT, x, rr, p3)
     assert torch.equal(p3, rr)
-    # bcast with input, coefficient from the device, mask
     A = torch.randn(n_z, X, Y, device=DEV)
     B = torch.randn(n_t, n_l, X // r, Y // r, device=DEV)
+    # factored residual: r = ra + rb kept as small arrays; ||r||^2 by the small-space identity; sweeps that form r
+    # on the fly give what the explicit sweeps give on the expanded r
+    def expand(a_, b_):
+        return a_.double()[None, None] + b_.double().repeat_interleave(r, 2).repeat_interleave(r, 3)[:, :, None]
+
+    k.new_factored_residual()
+    k.resid_update(A, B, 0.7, -1.3, 2.0, None, False)
+    r5 = expand(2.0 * 0.7 * A, 2.0 * -1.3 * B)
+    assert O.rel_l2(expand(k.ra, k.rb).cpu(), r5.cpu()) <= 1e-6
+    assert abs(float(k.scal[cabi.S_RR]) - float((r5 ** 2).sum())) <= 1e-6 * float((r5 ** 2).sum())
+    A2, B2 = torch.randn_like(A), torch.randn_like(B)
+    k.resid_update(A2, B2, 0.4, 0.9, -1.0, cabi.S_ALPHA, True)
+    r5 = r5 + expand(-al * 0.4 * A2, -al * 0.9 * B2)
+    assert O.rel_l2(expand(k.ra, k.rb).cpu(), r5.cpu()) <= 1e-6
+    assert abs(float(k.scal[cabi.S_RR]) - float((r5 ** 2).sum())) <= 1e-6 * float((r5 ** 2).sum())
+    # what the kernels see: the fp32 factors added in fp32
+    r5f = (k.ra[None, None] + k.rb.repeat_interleave(r, 2).repeat_interleave(r, 3)[:, :, None]).contiguous()
+    for mode in (cabi.SWEEP_XP, cabi.SWEEP_P, cabi.SWEEP_PINIT):
+        xe, pe, xf, pf = x.clone(), p.clone(), x.clone(), p.clone()
+        k.sweep(mode, xe, r5f, pe)
+        ref = (k.u.clone(), k.v.clone(), k.scal[cabi.S_UU:cabi.S_XP + 1].clone())
+        k.sweep(mode, xf, None, pf, factored=True)
+        assert torch.equal(xe, xf) and torch.equal(pe, pf), mode
+        assert torch.equal(ref[0], k.u) and torch.equal(ref[1], k.v)
+        # the per-slab fp32 dot products may be contracted into FMAs differently in the two instantiations
+        assert torch.allclose(ref[2], k.scal[cabi.S_UU:cabi.S_XP + 1], rtol=1e-6, atol=1e-6 * float(ref[2].abs().max()))
+    # bcast with input, coefficient from the device, mask
     mask = (torch.rand(n_z, X, Y, device=DEV) > 0.3).float()
     for inp, mk in ((rr, None), (None, mask), (rr, mask)):
         out = torch.empty_like(x)

@@ -50,12 +50,13 @@ def test_c2_full_size_50_iterations_vs_collapsed_fp64():
     assert err <= 1e-4
     # the residual the device tracked follows the fp64 one
     assert abs(float(f.k.scal[1]) - rs[-1]) <= 0.05 * rs[-1]
-    # the textbook schedule gives the same iterate
+    # the textbook schedule with an explicit 5-D residual gives the same iterate
     del x0
-    f2 = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, defer_x=False)
+    f2 = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, defer_x=False, residual="explicit")
     x2, _, _ = f2(50, return_numpy=False)
     d = float(torch.linalg.vector_norm((x2 - x).double().flatten()) / torch.linalg.vector_norm(x.double().flatten()))
-    assert d <= 2e-6, d
+    print(f"factored/deferred vs explicit/textbook: rel-L2 = {d:.3e}")
+    assert d <= 5e-6, d
 
 
 def test_cells_like_mid_size_vs_oracle_with_tolerance():
