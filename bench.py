@@ -4,6 +4,8 @@
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one CG iteration (fusion.py:439-456) on synthetic inputs already resident in HBM.
+The timed loop is run twice in one invocation: with the library's default factored residual (headline `value`,
+`roofline`) and with the residual as an explicit third 5-D vector (`other_residual_mode`); --single times one only.
 N = 1: BASELINE.json configs[1] (t256 x l16 x z16 x 128 x 128, r = 4).  N > 1: weak scaling, the
 same 16-plane slab per GPU (nZ = 16 N), z-sharded, one RCCL all-reduce of the spc-sized RD partial
 plus two scalar all-reduces per iteration.  Rank 0 prints ONE JSON line.
@@ -128,6 +130,7 @@ def main():
     ap.add_argument("--residual", default="factored", choices=["factored", "explicit"],
                     help="factored (default): r kept as its two small-space factors, 4N words/iter | explicit: r is a "
                          "third 5-D vector, 7N words/iter")
+    ap.add_argument("--single", action="store_true", help="time only --residual, not the other representation as well")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--target-blocks", type=int, default=0)
     a = ap.parse_args()
@@ -153,11 +156,6 @@ def main():
     n_t, n_l, nz_gpu, xy, r = WORKLOADS[a.workload]
     n_z = nz_gpu * world
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
-    f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
-                 mask_noise=False, total_energy=1, device=dev, seed=42, group=group, defer_x=not a.no_defer,
-                 target_blocks=a.target_blocks, residual=a.residual)
-    n_local = f.k.N
-    n_total = n_local * world
 
     def fence():
         torch.cuda.synchronize()
@@ -165,43 +163,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    f.start()
-    f.iterate(a.warmup)
-    f.k.timing = {}
-    fence()
-    t0 = time.perf_counter()
-    f.iterate(a.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    timing, f.k.timing = f.k.timing, None
-    f.finish()  # raises if the residual ever went non-finite
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    def run(residual):
+        """Construct, warm up, time exactly a.steps iterations of one residual mode; max over ranks."""
+        f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
+                     mask_noise=False, total_energy=1, device=dev, seed=42, group=group, defer_x=not a.no_defer,
+                     target_blocks=a.target_blocks, residual=residual)
+        f.start()
+        f.iterate(a.warmup)
+        f.k.timing = {}
+        fence()
+        t0 = time.perf_counter()
+        f.iterate(a.steps)
+        fence()
+        dt = time.perf_counter() - t0
+        timing, f.k.timing = f.k.timing, None
+        f.finish()  # raises if the residual ever went non-finite
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        # per-iteration time of each entry point from the HIP events recorded on the launch stream inside the
+        # timed region (a z-sharded sweep is cut into several launches: sum them)
+        kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in timing.items()}
+        fact = residual == "factored"
+        sweep_name = ("sweep2" if a.no_defer else "sweep1") + ("f" if fact else "")
+        # words the sweep must move (DESIGN.md): x, p read + written (deferred x update) or p read + written, plus
+        # the read of r when it is an explicit 5-D vector
+        sweep_words = (2 if a.no_defer else 4) + (0 if fact else 1)
+        res = {"dt": dt, "its": a.steps / dt, "kern": kern, "sweep_ms": kern[sweep_name],
+               "sweep_bytes": sweep_words * 4 * f.k.N,
+               "iter_words": sweep_words + (3 if a.no_defer else 0) + (0 if fact else 2),   # + dfx_axpy, + dfx_bcast
+               "launches": len(timing[sweep_name]) // a.steps, "zc": f.k.plan.zc, "n_local": f.k.N,
+               "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "cpb", "n_blocks")}}
+        del f
+        torch.cuda.empty_cache()
+        return res
 
-    # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
-    # per-iteration time of each entry point (a z-sharded sweep is cut into several launches: sum them)
-    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in timing.items()}
-    fact = a.residual == "factored"
-    sweep_name = ("sweep2" if a.no_defer else "sweep1") + ("f" if fact else "")
-    sweep_ms = kern[sweep_name]
-    # words the sweep must move: x, p read + written (deferred x update) or p read + written, plus the
-    # read of r when it is an explicit 5-D vector
-    sweep_words = (2 if a.no_defer else 4) + (0 if fact else 1)
-    sweep_bytes = sweep_words * 4 * n_local
-    iter_words = sweep_words + (3 if a.no_defer else 0) + (0 if fact else 2)   # + dfx_axpy, + dfx_bcast
-    ach = sweep_bytes / (sweep_ms * 1e-3) / 1e9
-    its = a.steps / dt
-    # HBM bytes per launch from the committed PMC passes of this same command (profiles/): counters cannot be
-    # collected from inside the process being profiled, so the figure is read back, for the workload it was taken on
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pmc["workload"] == a.workload and world == 1 and not a.no_defer:
-            traffic = pmc["kernels"][f"k_sweep_fast<XP,{f.k.plan.zc},r{r},{a.residual}>"]["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    def roofline(res, residual, traffic):
+        ach = res["sweep_bytes"] / (res["sweep_ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": f"k_sweep_fast<{'P' if a.no_defer else 'XP'},{res['zc']},r{r},{residual}>",
+                "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "traffic": traffic, "bytes_per_launch": res["sweep_bytes"], "avg_launch_ms": res["sweep_ms"]}
+
+    def pmc_traffic(residual, zc):
+        # HBM bytes per launch from the committed PMC passes of this same command (profiles/): counters cannot be
+        # collected from inside the process being profiled, so the figure is read back, for the workload it was taken on
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pmc["workload"] == a.workload and world == 1 and not a.no_defer:
+                return pmc["kernels"][f"k_sweep_fast<XP,{zc},r{r},{residual}>"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
+        return None
+
+    main_res = run(a.residual)
+    other = "explicit" if a.residual == "factored" else "factored"
+    other_res = None if a.single else run(other)
+    n_local = main_res["n_local"]
+    n_total = n_local * world
+    its, dt = main_res["its"], main_res["dt"]
     out = {
         "metric": "FusionCG iters/sec + achieved HBM GB/s vs peak, 5D fp32 (t,l,z,x,y), 1-8 GPU",
         # whole-job aggregate: every rank advances its 16-plane slab by one iteration per step, so the job does
@@ -215,21 +235,25 @@ def main():
                    "value_definition": "CG iterations/s x z-shards (slab-iterations/s): equals iterations/s of the "
                                        "configs[1] volume at 1 GPU; iters_per_s is the iteration rate of the whole "
                                        "sharded volume", "x_update": "textbook" if a.no_defer else "deferred",
-                   "residual": a.residual, "words_moved_per_iteration": f"{iter_words} N",
-                   "sweep_launches_per_iteration": len(timing[sweep_name]) // a.steps,
-                   "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "cpb", "n_blocks")}},
+                   "residual": a.residual, "words_moved_per_iteration": f"{main_res['iter_words']} N",
+                   "sweep_launches_per_iteration": main_res["launches"], "plan": main_res["plan"]},
         # whole iteration, all GPUs: SURVEY 8(d) prices an iteration at 32 N bytes and asks for that basis to be quoted
         # as "effective"; the build moves fewer (16 N with the factored residual), so "effective" may exceed the peak:
         # the honest bandwidth figure is hbm_moved_GBps and the per-kernel roofline below
         "hbm_effective_GBps": 32.0 * n_total * its / 1e9,
         "hbm_effective_frac_of_peak": 32.0 * n_local * its / 1e9 / HBM_PEAK_GBPS,
-        "hbm_moved_GBps": 4.0 * iter_words * n_total * its / 1e9,
-        "kernel_ms": kern,
-        "roofline": {"bound": "hbm",
-                     "kernel": f"k_sweep_fast<{'P' if a.no_defer else 'XP'},{f.k.plan.zc},r{r},{a.residual}>",
-                     "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                     "traffic": traffic, "bytes_per_launch": sweep_bytes, "avg_launch_ms": sweep_ms},
+        "hbm_moved_GBps": 4.0 * main_res["iter_words"] * n_total * its / 1e9,
+        "kernel_ms": main_res["kern"],
+        "roofline": roofline(main_res, a.residual, pmc_traffic(a.residual, main_res["zc"])),
     }
+    if other_res is not None:
+        # the same timed loop with the other residual representation, measured in this same invocation
+        o = other_res
+        out["other_residual_mode"] = {
+            "residual": other, "value": o["its"] * world, "iters_per_s": o["its"], "ms_per_step": o["dt"] / a.steps * 1e3,
+            "words_moved_per_iteration": f"{o['iter_words']} N",
+            "hbm_moved_GBps": 4.0 * o["iter_words"] * n_total * o["its"] / 1e9, "kernel_ms": o["kern"],
+            "roofline": roofline(o, other, pmc_traffic(other, o["zc"]))}
     if rank == 0:
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_l, n_z, xy, r, n_total)

@@ -750,43 +750,72 @@ __global__ __launch_bounds__(256) void k_fold(const double *parts, int n_rows, i
 // form r = ra[z,x,y] + rb[t,l,x/r,y/r]: it is kept as those two small arrays and never stored as a 5-D vector.
 //   ||r||^2 = M * sum ra^2 + 2 * sum_{t,l,xb,yb} rb * zab[xb,yb] + nZ r^2 * sum rb^2,   zab = sum_z sum_block ra
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resid_a(float *ra, const float *A, long long n, float sa, float coef_host,
-                                                 const double *coef_dev, int accumulate, double *part) {
+// ra update + sum ra^2 + zab in one pass.  Workgroup = 16 blocks x 16 z-lanes: thread (b, zz) walks planes
+// zz, zz+16, ... of block b (r rows of r contiguous floats: neighbouring threads touch neighbouring segments).
+__global__ __launch_bounds__(256) void k_resid_az(float *ra, const float *A, float *zab, Geo q, float sa,
+                                                  float coef_host, const double *coef_dev, int accumulate,
+                                                  double *part) {
+    __shared__ float sh[16][17];
     const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f) * sa;
+    const int b = threadIdx.x & 15, zz = threadIdx.x >> 4;
+    const int groups = (int)((q.Ps + 15) / 16);
     double acc = 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float v = (accumulate ? ra[i] : 0.f) + c * A[i];
-        ra[i] = v;
-        acc += (double)v * (double)v;
+    for (int gi = blockIdx.x; gi < groups; gi += gridDim.x) {
+        const int j = gi * 16 + b;
+        float bs = 0.f;
+        if (j < q.Ps) {
+            const int xb = j / q.Ys, yb = j - xb * q.Ys;
+            for (int z = zz; z < q.nZ; z += 16) {
+                const long long o = (long long)z * q.P + (long long)(xb * q.r) * q.Y + yb * q.r;
+                for (int dx = 0; dx < q.r; ++dx)
+                    for (int dy = 0; dy < q.r; ++dy) {
+                        const long long i = o + (long long)dx * q.Y + dy;
+                        const float v = (accumulate ? ra[i] : 0.f) + c * A[i];
+                        ra[i] = v;
+                        acc += (double)v * (double)v;
+                        bs += v;
+                    }
+            }
+        }
+        sh[zz][b] = bs;
+        __syncthreads();
+        if (threadIdx.x < 16 && j < q.Ps) {
+            float s = 0.f;
+            for (int k = 0; k < 16; ++k) s += sh[k][threadIdx.x];
+            zab[j] = s;
+        }
+        __syncthreads();
     }
     block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
 }
 
-__global__ __launch_bounds__(256) void k_resid_zab(const float *ra, float *zab, Geo q) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < q.Ps; j += stride) {
-        const int xb = (int)(j / q.Ys), yb = (int)(j - (long long)xb * q.Ys);
-        double s = 0;
-        for (int z = 0; z < q.nZ; ++z)
-            for (int dx = 0; dx < q.r; ++dx)
-                for (int dy = 0; dy < q.r; ++dy)
-                    s += (double)ra[(long long)z * q.P + (long long)(xb * q.r + dx) * q.Y + yb * q.r + dy];
-        zab[j] = (float)s;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, const float *zab, long long n,
-                                                 long long Ps, float sb, float coef_host, const double *coef_dev,
-                                                 int accumulate, double *part) {
+// rb update + sum rb^2 + sum rb*zab: a workgroup takes whole rows (t,l) of rb, so the zab index needs no modulo
+__global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, const float *zab, int M, int Ps,
+                                                 float sb, float coef_host, const double *coef_dev, int accumulate,
+                                                 double *part) {
     const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f) * sb;
     double a2 = 0, ab = 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float v = (accumulate ? rb[i] : 0.f) + c * B[i];
-        rb[i] = v;
-        a2 += (double)v * (double)v;
-        ab += (double)v * (double)zab[i % Ps];
+    const bool vec = (Ps % 4 == 0) && ((((uintptr_t)rb | (uintptr_t)B | (uintptr_t)zab) & 15) == 0);
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        float *row = rb + (long long)m * Ps;
+        const float *brow = B + (long long)m * Ps;
+        if (vec) {
+            for (int j = 4 * threadIdx.x; j < Ps; j += 4 * 256) {
+                f4 v = c * ld4(brow + j);
+                if (accumulate) v += ld4(row + j);
+                st4(row + j, v);
+                const f4 zv = ld4(zab + j);
+                a2 += (double)dot4(v, v);
+                ab += (double)dot4(v, zv);
+            }
+        } else {
+            for (int j = threadIdx.x; j < Ps; j += 256) {
+                const float v = (accumulate ? row[j] : 0.f) + c * brow[j];
+                row[j] = v;
+                a2 += (double)v * (double)v;
+                ab += (double)v * (double)zab[j];
+            }
+        }
     }
     block_store3(0.0, a2, ab, part + (long long)blockIdx.x * DFX_NPART);
 }
@@ -1269,14 +1298,14 @@ int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, co
     if (int rc = make_geo(g, &q)) return rc;
     if (!ra || !rb || !A || !B || !zab || !scal || !part) return fail(DFX_EINVAL, "dfx_resid_update: NULL buffer");
     hipStream_t st = (hipStream_t)stream;
-    const long long nb_total = (long long)q.M * q.Ps;
-    const int nba = ew_blocks(q.S, 4) > DFX_EW_MAXBLOCKS / 2 ? DFX_EW_MAXBLOCKS / 2 : ew_blocks(q.S, 4);
-    const int nbb = ew_blocks(nb_total, 4) > DFX_EW_MAXBLOCKS / 2 ? DFX_EW_MAXBLOCKS / 2 : ew_blocks(nb_total, 4);
-    hipLaunchKernelGGL(k_resid_a, dim3(nba), dim3(256), 0, st, ra, A, q.S, sa, coef_host, coef_dev, accumulate, part);
+    if (q.Ps > 0x7fffffffLL) return fail(DFX_EINVAL, "dfx_resid_update: plane too large");
+    const int groups = (int)((q.Ps + 15) / 16);
+    const int nba = groups < DFX_EW_MAXBLOCKS / 2 ? groups : DFX_EW_MAXBLOCKS / 2;
+    const int nbb = q.M < DFX_EW_MAXBLOCKS / 2 ? q.M : DFX_EW_MAXBLOCKS / 2;
+    hipLaunchKernelGGL(k_resid_az, dim3(nba), dim3(256), 0, st, ra, A, zab, q, sa, coef_host, coef_dev, accumulate,
+                       part);
     DFX_LAUNCH_CHECK("dfx_resid_update(a)");
-    hipLaunchKernelGGL(k_resid_zab, dim3(ew_blocks(q.Ps, 1)), dim3(256), 0, st, (const float *)ra, zab, q);
-    DFX_LAUNCH_CHECK("dfx_resid_update(zab)");
-    hipLaunchKernelGGL(k_resid_b, dim3(nbb), dim3(256), 0, st, rb, B, (const float *)zab, nb_total, q.Ps, sb,
+    hipLaunchKernelGGL(k_resid_b, dim3(nbb), dim3(256), 0, st, rb, B, (const float *)zab, q.M, (int)q.Ps, sb,
                        coef_host, coef_dev, accumulate, part + (long long)nba * DFX_NPART);
     DFX_LAUNCH_CHECK("dfx_resid_update(b)");
     hipLaunchKernelGGL(k_resid_rr, dim3(1), dim3(256), 0, st, (const double *)part, nba + nbb, (double)q.M,

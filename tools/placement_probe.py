@@ -1,0 +1,58 @@
+"""Does the duration of one sweep depend on WHERE its vectors were placed?  (DESIGN.md "open observation":
+the nZ = 4 slabs of configs 3 / 4 run in a fast or a slow mode, fixed per process.)
+
+Allocates the x, p pair several times inside ONE process - keeping or releasing the previous pairs so the driver hands
+out different physical ranges - and times dfx_sweep_factored(XP) on each pair.
+
+    python tools/placement_probe.py --shape 512,32,4,256,256 --rounds 8
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from datafusion_amd import _cabi as cabi  # noqa: E402
+from datafusion_amd.kernels import HipKernels  # noqa: E402
+
+
+def time_sweep(k, x, p, reps):
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        k.sweep(cabi.SWEEP_XP, x, None, p, factored=True)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="512,32,4,256,256")
+    ap.add_argument("--rounds", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--keep", type=int, default=3, help="keep at most this many earlier pairs allocated")
+    a = ap.parse_args()
+    shape = tuple(int(v) for v in a.shape.split(","))
+    k = HipKernels(*shape, 4, "cuda:0")
+    k.new_factored_residual()
+    k.ra.zero_(), k.rb.zero_()
+    nbytes = 4 * k.N
+    kept = []
+    for i in range(a.rounds):
+        x = torch.zeros(k.shape, device="cuda:0")
+        p = torch.zeros(k.shape, device="cuda:0")
+        ms = time_sweep(k, x, p, a.reps)
+        print(f"round {i}: x @0x{x.data_ptr():x} p @0x{p.data_ptr():x}  sweep {ms:.3f} ms = "
+              f"{4 * nbytes / ms / 1e6:.0f} GB/s", flush=True)
+        kept.append((x, p))
+        if len(kept) > a.keep:
+            kept.pop(0)
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

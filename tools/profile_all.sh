@@ -21,12 +21,29 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             short = k.split("(anonymous namespace)::")[1].split("(")[0] if "(anonymous namespace)::" in k else k[:50]
             print(c, short, "n=%d" % len(v), "avg_KiB=%.1f" % (sum(v) / len(v)))
             res.setdefault(short, {})[c] = sum(v) / len(v)
+import re
+MODES = {"0": "PROJECT", "1": "XP", "2": "P", "3": "PINIT"}
+def canon(k):
+    """k_sweep_fast<1, 8, 4, true> -> k_sweep_fast<XP,8,r4,factored> (the key bench.py looks up)."""
+    m = re.match(r"k_sweep_fast<(\d), (\d+), (\d+), (true|false)>", k)
+    if m:
+        return f"k_sweep_fast<{MODES[m.group(1)]},{m.group(2)},r{m.group(3)},{'factored' if m.group(4) == 'true' else 'explicit'}>"
+    return k
 out = {}
 for k, d in res.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        out[k] = {"FETCH_SIZE_KiB": d["FETCH_SIZE"], "WRITE_SIZE_KiB": d["WRITE_SIZE"],
-                  "traffic_bytes": int(d["FETCH_SIZE"] * 2 * 1024 + d["WRITE_SIZE"] * 1024)}
-json.dump(out, open(f"gpurun_out/pmc_{tag}_traffic.json", "w"), indent=1)
+        out[canon(k)] = {"FETCH_SIZE_KiB": d["FETCH_SIZE"], "WRITE_SIZE_KiB": d["WRITE_SIZE"],
+                         "traffic_bytes": int(d["FETCH_SIZE"] * 2 * 1024 + d["WRITE_SIZE"] * 1024)}
+N = 2 ** 30
+doc = {"workload": "c2",
+       "source": f"tools/profile_all.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
+                 "`python3 bench.py --no-cpu --steps 4 --warmup 1` (both residual modes run in that command)",
+       "correction": "MI355X_MICROARCH.md HBM section: counters are KiB; on gfx950 FETCH_SIZE reports 1/2 of a 16 B/lane "
+                     "coalesced streaming read -> doubled; WRITE_SIZE exact",
+       "kernels": out,
+       "algorithmic_bytes": {"k_sweep_fast<XP,8,r4,factored>": 16 * N, "k_sweep_fast<XP,8,r4,explicit>": 20 * N,
+                             "k_bcast_fast<8, 4, true, false>": 8 * N}}
+json.dump(doc, open(f"gpurun_out/pmc_{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/prof_${TAG}_kernel_stats.csv; head -8 $f | cut -c1-150
