@@ -26,7 +26,9 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6
 
 WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "c2": (256, 16, 16, 128, 4),
-    "c3z16": (512, 32, 16, 256, 4),      # 64 GiB / vector: the largest single-GPU anchor of config 3
+    "c3": (512, 32, 32, 256, 4),         # config 3 whole on ONE GPU: 128 GiB / vector, x + p = 256 GiB (factored residual only)
+    "c4": (256, 16, 32, 512, 4),         # config 4 whole on ONE GPU, same size
+    "c3z16": (512, 32, 16, 256, 4),      # 64 GiB / vector: half of config 3
     "c3g8": (512, 32, 4, 256, 4),        # config 3 as sharded over 8 GPUs (per-GPU slab)
     "c4g8": (256, 16, 4, 512, 4),        # config 4 as sharded over 8 GPUs (per-GPU slab)
     "cells": (64, 16, 20, 128, 4),       # README-like

@@ -1,8 +1,9 @@
-"""Numerical check at a volume no CPU restatement fits: the explicit fp32 HIP CG against the fp64 collapsed
+"""Numerical check at a volume no CPU restatement fits: the fp32 HIP CG (5-D x and p) against the fp64 collapsed
 (small-space) CG of oracle/fusion_oracle.py.  Default: t512 x l32 x z16 x 256 x 256
-(2^34 elements, 64 GiB per vector) on one MI355X.
+(2^34 elements, 64 GiB per vector) on one MI355X; with the factored residual BASELINE config 3 itself
+(--shape 512,32,32,256: 2^35 elements, 128 GiB per vector, x + p = 256 GiB) fits one GPU.
 
-    python tools/verify_large.py [--shape 512,32,16,256] [--iters 10]
+    python tools/verify_large.py [--shape 512,32,16,256] [--iters 10] [--residual factored|explicit]
 """
 import argparse
 import json
@@ -21,13 +22,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="512,32,16,256")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--residual", default="factored", choices=["factored", "explicit"])
     a = ap.parse_args()
     n_t, n_l, n_z, xy = map(int, a.shape.split(","))
     r, dev = 4, "cuda:0"
     w = {"spatial": 0.5, "spectro_temporal": 0.5}
     spc, cmos = O.synthetic_inputs(n_t, n_l, n_z, xy, r)
     t0 = time.time()
-    f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=dev)
+    f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=dev, residual=a.residual)
     f._project(f.x)
     u0, v0 = f.k.u.cpu().clone(), f.k.v.cpu().clone()
     sum_x0 = float(f.k.scal[15])
@@ -53,7 +55,7 @@ def main():
         num += ((x[t].double() - ref) ** 2).sum()
         den += (ref ** 2).sum()
     err = float(torch.sqrt(num / den))
-    out = {"shape": [n_t, n_l, n_z, xy, xy], "n_elements": f.k.N, "iterations": a.iters,
+    out = {"shape": [n_t, n_l, n_z, xy, xy], "n_elements": f.k.N, "iterations": a.iters, "residual": a.residual,
            "rel_l2_vs_fp64_collapsed": err, "rsnew_gpu": rs_gpu, "rsnew_fp64": rs[-1], "alpha_last_fp64": alphas[-1],
            "alpha_last_gpu": float(f.k.scal[3])}
     print(json.dumps(out), flush=True)
