@@ -237,9 +237,9 @@ class FusionCG(Fusion):
         r = ra[z,x,y] + rb[t,l,x/r,y/r] (include/dfx.h, dfx_resid_update) - one 4N-word pass per iteration and
         two resident 5-D vectors (x, p).  residual="explicit": r is a third 5-D vector updated by dfx_bcast
         (2N words) and read by the sweep (5N words), the literal transcription of fusion.py:446."""
-        super().__init__(*args, **kwargs)
         if residual not in ("factored", "explicit"):
             raise ValueError("residual must be 'factored' or 'explicit'")
+        super().__init__(*args, **kwargs)
         self.residual = residual
         self.w1 = self.weights["spatial"]
         self.w2 = self.weights["spectro_temporal"]

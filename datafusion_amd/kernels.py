@@ -92,6 +92,20 @@ class HipKernels:
             self.rb = torch.empty((n_t, n_l, self.Xs, self.Ys), dtype=torch.float32, device=self.device)
             self.zab = torch.empty((self.Xs, self.Ys), dtype=torch.float32, device=self.device)
 
+    @staticmethod
+    def _slice_bounds(cpb: int, k: int):
+        """Cut cpb chunks into k non-empty bands of decreasing length (weights k, k-1, ..., 1): every band's
+        all-reduce but the last overlaps the rest of the sweep, so the last one - the exposed one - is the shortest."""
+        total = k * (k + 1) // 2
+        bounds, acc = [0], 0
+        for j in range(k):
+            acc += k - j
+            lo = bounds[-1] + 1                      # at least one chunk per band
+            hi = cpb - (k - 1 - j)                   # leave one for every band still to come
+            bounds.append(min(max(round(cpb * acc / total), lo), hi))
+        bounds[-1] = cpb
+        return bounds
+
     def _chk(self, *ts):
         for t in ts:
             if t is not None:
@@ -113,7 +127,7 @@ class HipKernels:
         P = self.plan
         k = max(1, min(int(slices), P.cpb, cabi.MAX_SLICES)) if P.fast else 1
         gz = P.n_chunks // P.cpb
-        bounds = [P.cpb * j // k for j in range(k + 1)]
+        bounds = self._slice_bounds(P.cpb, k)
         vrows = self.v.view(self.M, self.Xs * self.Ys)
         if factored:
             assert r is None and self.ra is not None and mode != cabi.SWEEP_PROJECT

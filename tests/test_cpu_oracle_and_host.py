@@ -121,7 +121,7 @@ def test_header_constants_match_python_mirror():
     from datafusion_amd import _cabi as cabi
     src = open(os.path.join(ROOT, "include", "dfx.h")).read()
     for name in ("RSOLD", "RSNEW", "PAP", "ALPHA", "BETA", "TOL", "UU", "PP", "XX", "XP", "VV", "RR", "XXNEW",
-                 "NONFINITE", "ITER", "SUM", "SCALE", "LOSS1", "LOSS2", "ADAM_DD", "ADAM_XX"):
+                 "NONFINITE", "ITER", "SUM", "SCALE", "LOSS1", "LOSS2", "ADAM_DD", "ADAM_XX", "RA2", "RB2", "RAB"):
         m = re.search(rf"DFX_S_{name}\s*=\s*(\d+)", src)
         assert m and int(m.group(1)) == getattr(cabi, "S_" + name), name
     assert int(re.search(r"DFX_NSCAL\s*=\s*(\d+)", src).group(1)) == cabi.NSCAL
@@ -167,6 +167,29 @@ def cabi_neg():
     return -1
 
 
+def test_factored_entry_points_validate_arguments_before_touching_the_gpu():
+    from datafusion_amd import _cabi as cabi
+    lib = cabi.lib()
+    g, p = cabi.Geom(4, 3, 2, 16, 16, 4, 0), cabi.Plan()
+    assert lib.dfx_plan_make(C.byref(g), 0, C.byref(p)) == 0
+    one = C.c_void_p(4096)   # never dereferenced: every call below must fail in its argument checks
+    assert lib.dfx_resid_update(C.byref(g), None, one, one, one, 1.0, 1.0, 1.0, None, 0, one, one, one, None) < 0
+    assert b"NULL" in lib.dfx_last_error()
+    assert lib.dfx_resid_update(C.byref(g), one, one, one, one, 1.0, 1.0, 1.0, None, 0, None, one, one, None) < 0
+    args = (C.byref(g), C.byref(p), one, one, one, one, one, one, one, one, 0, p.cpb, 0, 1, None)
+    assert lib.dfx_sweep_factored(cabi.SWEEP_PROJECT, *args) < 0          # nothing to factor in a projection
+    bad = list(args)
+    bad[3] = None                                                          # ra missing
+    assert lib.dfx_sweep_factored(cabi.SWEEP_XP, *bad) < 0
+    bad = list(args)
+    bad[11] = p.cpb + 1                                                    # chunk range outside the plan
+    assert lib.dfx_sweep_factored(cabi.SWEEP_XP, *bad) < 0
+    with pytest.raises(ValueError, match="residual"):
+        from datafusion_amd import FusionCG
+        FusionCG(np.ones((2, 2, 2, 2), np.float32), np.ones((2, 8, 8), np.float32),
+                 weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="zeros", device="cpu", residual="nope")
+
+
 def test_product_refuses_cpu_device():
     from datafusion_amd import FusionCG, _cabi as cabi
     spc, cmos = O.synthetic_inputs(2, 2, 2, 8, 4)
@@ -190,13 +213,15 @@ def cpu_backend(monkeypatch):
     monkeypatch.setattr(fusion.Fusion, "_backend_cls", CpuStandIn)
 
 
+@pytest.mark.parametrize("residual", ["factored", "explicit"])
 @pytest.mark.parametrize("defer", [True, False])
 @pytest.mark.parametrize("name,iters,kw", CG_CASES[:2] + CG_CASES[5:])
-def test_host_logic_cg_vs_goldens(golden, cpu_backend, name, iters, kw, defer):
+def test_host_logic_cg_vs_goldens(golden, cpu_backend, name, iters, kw, defer, residual):
     from datafusion_amd import FusionCG
     g = golden(name)
     k = iters[-1]
-    f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu", defer_x=defer, **kw)
+    f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu", defer_x=defer,
+                 residual=residual, **kw)
     assert O.rel_l2(f.x, g["x0"]) <= 1e-6
     x, _, _ = f(k)
     assert f.curr_iter == k and O.rel_l2(x, g[f"x_{k}"]) <= 2e-5
@@ -295,3 +320,15 @@ def test_integration_doc_struct_layout_matches_header():
     body = re.search(r"typedef struct dfx_plan \{(.*?)\} dfx_plan;", hdr, flags=re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     assert re.findall(r"int(?:32|64)_t\s+(\w+);", body) == [f[0] for f in cabi.Plan._fields_]
+
+
+def test_sweep_slice_bounds_decrease_and_cover():
+    """The bands a z-sharded sweep is cut into: non-empty, covering, and the last (whose all-reduce is exposed) the
+    shortest."""
+    from datafusion_amd.kernels import HipKernels
+    for cpb in (1, 2, 3, 5, 8, 64, 256):
+        for k in range(1, min(cpb, 16) + 1):
+            b = HipKernels._slice_bounds(cpb, k)
+            d = [b[i + 1] - b[i] for i in range(k)]
+            assert b[0] == 0 and b[-1] == cpb and len(b) == k + 1 and min(d) >= 1
+            assert d[-1] == min(d)
