@@ -143,3 +143,32 @@ def test_collectives_through_real_rccl_one_rank():
     assert it == pb.curr_iter and O.rel_l2(x, xo) <= 2e-5
     pb = O.prepare(spc, cmos, weights=W, init_type="baseline", tol=None)
     assert O.rel_l2(xa, O.adam(pb, 1e-7, 3)) <= 2e-5
+
+
+def test_readme_flow_on_a_synthetic_acquisition(tmp_path):
+    """BASELINE.json configs[0] (the README example: load_data(npz, max_xy_size) -> FusionCG(tol=3e-3)(20)).
+    The Zenodo file is not available offline: a cells-like acquisition of the same layout (utils.py:411-427:
+    keys spc, cmos, time_axis, spectral_axis; cmos stored larger than max_xy_size) stands in for it, and the
+    result is checked against the CPU oracle fed with the same loaded arrays."""
+    from datafusion_amd import FusionCG, load_data
+    spc, cmos = O.cells_like_inputs(12, 16, 6, 64, 4, seed=9)            # (t, l, 16, 16), (z, 64, 64)
+    spc, cmos = np.asarray(spc, dtype=np.float32), np.asarray(cmos, dtype=np.float32)
+    big = torch.nn.functional.interpolate(torch.from_numpy(cmos)[None], scale_factor=2, mode="bilinear",
+                                          align_corners=False)[0]
+    path = tmp_path / "cells_synth.npz"
+    np.savez(path, spc=spc, cmos=big.numpy(), time_axis=np.linspace(0, 12.5, 12),
+             spectral_axis=np.linspace(500, 700, 16))
+    spc_l, cmos_l, t_ax, l_ax = load_data(path, max_xy_size=64)
+    assert spc_l.shape == (12, 16, 16, 16) and cmos_l.shape == (6, 64, 64) and len(t_ax) == 12 and len(l_ax) == 16
+    w = {"spatial": 0.5, "spectro_temporal": 0.5}
+    f = FusionCG(spc_l, cmos_l, weights=w, init_type="baseline", tol=3e-3, mask_noise=False, total_energy=1,
+                 device=DEV, seed=42)
+    x, spc_n, cmos_n = f(max_iterations=20)
+    pb = O.prepare(torch.from_numpy(spc_l.astype(np.float32)), torch.from_numpy(cmos_l.astype(np.float32)), weights=w,
+                   init_type="baseline", tol=3e-3)
+    xo = O.cg(pb, 20, with_loss=False)
+    assert f.curr_iter == pb.curr_iter
+    assert x.shape == (12, 16, 6, 64, 64) and O.rel_l2(x, xo) <= 2e-5
+    assert O.rel_l2(spc_n, pb.spc) <= 1e-6 and O.rel_l2(cmos_n, pb.cmos) <= 1e-6
+    # the slices the README plots afterwards (cells.ipynb): intensity image and global spectrum / decay
+    assert O.rel_l2(f.marginals("tl").cpu(), torch.from_numpy(x).double().sum((0, 1))) <= 1e-6
