@@ -44,7 +44,7 @@ def synthetic(n_t, n_l, n_z, xy, r, seed=0):
     return spc, cmos
 
 
-def cpu_baseline(n_l, n_z, xy, r, full_n, budget_s=20.0):
+def cpu_baseline(n_l, n_z, xy, r, full_n, budget_s=15.0):
     """The oracle (eager-faithful torch-CPU port of fusion.py:423-456, per-iteration loss included)
     timed on this host on a bounded sample: same geometry, fewer time bins; scaled 1/N to the
     full workload.  Reported, never the target."""
@@ -59,7 +59,7 @@ def cpu_baseline(n_l, n_z, xy, r, full_n, budget_s=20.0):
         O.cg(pb, 2)          # each call pays b and r0 once, like a reference call would
         iters += 2
         dt = time.perf_counter() - t0
-        if dt > budget_s or iters >= 20:
+        if dt > budget_s or iters >= 200:
             break
     n_sample = n_t * n_l * n_z * xy * xy
     its = iters / dt
