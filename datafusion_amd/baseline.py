@@ -4,6 +4,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import hostcopy
 from .kernels import HipKernels
 
 
@@ -24,4 +25,4 @@ def baseline(cmos, spc, device: str = "cuda", return_numpy: bool = True):
     zw = (cmos / cmos.sum(dim=0, keepdim=True)).contiguous()  # baseline.py:46 (small array)
     x = k.new_vector()
     k.baseline_init(spc, zw, x, 1.0, None)                    # baseline.py:48-50
-    return x.cpu().numpy() if return_numpy else x
+    return hostcopy.to_numpy(x) if return_numpy else x

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from . import _cabi as cabi
 from .dist import ShardComm, z_partition
-from . import kernels
+from . import hostcopy, kernels
 from .kernels import HipKernels
 
 
@@ -222,7 +222,7 @@ class Fusion:
     def _result(self, return_numpy: bool):
         x = self.x.detach() if isinstance(self.x, torch.Tensor) else self.x
         if return_numpy:                                                     # fusion.py:489-496
-            return x.cpu().numpy(), self.spc.cpu().numpy(), self.cmos.cpu().numpy()
+            return hostcopy.to_numpy(x), self.spc.cpu().numpy(), self.cmos.cpu().numpy()
         return self.x, self.spc, self.cmos
 
     def __call__(self, *args, **kwargs):

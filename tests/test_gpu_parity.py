@@ -367,3 +367,22 @@ def test_operator_mirrors_match_reference_semantics():
     a = 0.3 * f.T.T(f.S.T(f.S(f.T(xg)))) + 0.7 * f.D.T(f.R.T(f.R(f.D(xg))))
     pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
     assert O.rel_l2(a.cpu(), O.normal_op(pb, x)) <= 1e-6
+
+
+def test_result_host_copy_is_exact_and_shaped():
+    """return_numpy=True goes through the pipelined pinned-bounce copy (datafusion_amd/hostcopy.py) for large volumes."""
+    from datafusion_amd import hostcopy
+    torch.manual_seed(5)
+    old = hostcopy._CHUNK_BYTES
+    try:
+        hostcopy._CHUNK_BYTES = 1 << 20                      # 1 MiB chunks: ragged tail, many ping-pong rounds
+        x = torch.randn(7, 3, 5, 36, 100, device=DEV)        # 1.5 MB... below the 4-chunk threshold: plain path
+        assert np.array_equal(hostcopy.to_numpy(x), x.cpu().numpy())
+        x = torch.randn(37, 5, 6, 64, 68, device=DEV)        # 19.3 MB, not a multiple of the chunk
+        a = hostcopy.to_numpy(x)
+        assert a.shape == tuple(x.shape) and a.dtype == np.float32 and np.array_equal(a, x.cpu().numpy())
+        x.zero_()                                            # the result must not alias device or bounce memory
+        b = hostcopy.to_numpy(torch.ones_like(x))
+        assert float(np.abs(a).sum()) > 0 and float(b.min()) == 1.0
+    finally:
+        hostcopy._CHUNK_BYTES = old

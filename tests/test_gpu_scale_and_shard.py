@@ -172,3 +172,24 @@ def test_readme_flow_on_a_synthetic_acquisition(tmp_path):
     assert O.rel_l2(spc_n, pb.spc) <= 1e-6 and O.rel_l2(cmos_n, pb.cmos) <= 1e-6
     # the slices the README plots afterwards (cells.ipynb): intensity image and global spectrum / decay
     assert O.rel_l2(f.marginals("tl").cpu(), torch.from_numpy(x).double().sum((0, 1))) <= 1e-6
+
+
+def test_bench_prints_one_contract_line():
+    """bench.py's stdout is exactly one JSON line with the fields the driver reads (tiny workload, child process)."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup",
+                        "1"], capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["unit"] == "it/s" and d["value"] > 0 and d["dtype"] == "f32" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    assert d["config"]["residual"] == "factored" and d["other_residual_mode"]["residual"] == "explicit"
