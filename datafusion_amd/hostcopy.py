@@ -29,7 +29,10 @@ def to_numpy(x: torch.Tensor) -> np.ndarray:
         return x.cpu().numpy()
     flat = x.reshape(-1)
     n, step = flat.numel(), _CHUNK_BYTES // 4
-    bufs, stream = _bounce(x.device, step)
+    try:
+        bufs, stream = _bounce(x.device, step)
+    except RuntimeError:            # no pinned memory to be had (ulimit -l, container limits): plain staged copy
+        return x.cpu().numpy()
     out = torch.empty(n, dtype=torch.float32)            # pageable; its pages are first touched by the copy threads
     stream.wait_stream(torch.cuda.current_stream(x.device))
     n_chunks = (n + step - 1) // step
