@@ -752,17 +752,17 @@ __global__ __launch_bounds__(256) void k_fold(const double *parts, int n_rows, i
 // ------------------------------------------------------------------------------------------
 // ra update + sum ra^2 + zab in one pass.  Workgroup = 16 blocks x 16 z-lanes: thread (b, zz) walks planes
 // zz, zz+16, ... of block b (r rows of r contiguous floats: neighbouring threads touch neighbouring segments).
-__global__ __launch_bounds__(256) void k_resid_az(float *ra, const float *A, float *zab, Geo q, float sa,
+__global__ __launch_bounds__(256) void k_resid_az(float *ra, const float *A, double *zab, Geo q, float sa,
                                                   float coef_host, const double *coef_dev, int accumulate,
                                                   double *part) {
-    __shared__ float sh[16][17];
+    __shared__ double sh[16][17];
     const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f) * sa;
     const int b = threadIdx.x & 15, zz = threadIdx.x >> 4;
     const int groups = (int)((q.Ps + 15) / 16);
     double acc = 0;
     for (int gi = blockIdx.x; gi < groups; gi += gridDim.x) {
         const int j = gi * 16 + b;
-        float bs = 0.f;
+        double bs = 0;   // fp64: ||r||^2 is a difference of the three sums when ra and rb partly cancel
         if (j < q.Ps) {
             const int xb = j / q.Ys, yb = j - xb * q.Ys;
             for (int z = zz; z < q.nZ; z += 16) {
@@ -773,14 +773,14 @@ __global__ __launch_bounds__(256) void k_resid_az(float *ra, const float *A, flo
                         const float v = (accumulate ? ra[i] : 0.f) + c * A[i];
                         ra[i] = v;
                         acc += (double)v * (double)v;
-                        bs += v;
+                        bs += (double)v;
                     }
             }
         }
         sh[zz][b] = bs;
         __syncthreads();
         if (threadIdx.x < 16 && j < q.Ps) {
-            float s = 0.f;
+            double s = 0;
             for (int k = 0; k < 16; ++k) s += sh[k][threadIdx.x];
             zab[j] = s;
         }
@@ -790,12 +790,12 @@ __global__ __launch_bounds__(256) void k_resid_az(float *ra, const float *A, flo
 }
 
 // rb update + sum rb^2 + sum rb*zab: a workgroup takes whole rows (t,l) of rb, so the zab index needs no modulo
-__global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, const float *zab, int M, int Ps,
+__global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, const double *zab, int M, int Ps,
                                                  float sb, float coef_host, const double *coef_dev, int accumulate,
                                                  double *part) {
     const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f) * sb;
     double a2 = 0, ab = 0;
-    const bool vec = (Ps % 4 == 0) && ((((uintptr_t)rb | (uintptr_t)B | (uintptr_t)zab) & 15) == 0);
+    const bool vec = (Ps % 4 == 0) && ((((uintptr_t)rb | (uintptr_t)B) & 15) == 0);
     for (int m = blockIdx.x; m < M; m += gridDim.x) {
         float *row = rb + (long long)m * Ps;
         const float *brow = B + (long long)m * Ps;
@@ -804,16 +804,15 @@ __global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, cons
                 f4 v = c * ld4(brow + j);
                 if (accumulate) v += ld4(row + j);
                 st4(row + j, v);
-                const f4 zv = ld4(zab + j);
-                a2 += (double)dot4(v, v);
-                ab += (double)dot4(v, zv);
+                a2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+                ab += ((double)v.x * zab[j] + (double)v.y * zab[j + 1]) + ((double)v.z * zab[j + 2] + (double)v.w * zab[j + 3]);
             }
         } else {
             for (int j = threadIdx.x; j < Ps; j += 256) {
                 const float v = (accumulate ? row[j] : 0.f) + c * brow[j];
                 row[j] = v;
                 a2 += (double)v * (double)v;
-                ab += (double)v * (double)zab[j];
+                ab += (double)v * zab[j];
             }
         }
     }
@@ -1292,7 +1291,7 @@ int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, floa
 }
 
 int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
-                     float coef_host, const double *coef_dev, int32_t accumulate, float *zab, double *scal,
+                     float coef_host, const double *coef_dev, int32_t accumulate, double *zab, double *scal,
                      double *part, void *stream) {
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
@@ -1305,7 +1304,7 @@ int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, co
     hipLaunchKernelGGL(k_resid_az, dim3(nba), dim3(256), 0, st, ra, A, zab, q, sa, coef_host, coef_dev, accumulate,
                        part);
     DFX_LAUNCH_CHECK("dfx_resid_update(a)");
-    hipLaunchKernelGGL(k_resid_b, dim3(nbb), dim3(256), 0, st, rb, B, (const float *)zab, q.M, (int)q.Ps, sb,
+    hipLaunchKernelGGL(k_resid_b, dim3(nbb), dim3(256), 0, st, rb, B, (const double *)zab, q.M, (int)q.Ps, sb,
                        coef_host, coef_dev, accumulate, part + (long long)nba * DFX_NPART);
     DFX_LAUNCH_CHECK("dfx_resid_update(b)");
     hipLaunchKernelGGL(k_resid_rr, dim3(1), dim3(256), 0, st, (const double *)part, nba + nbb, (double)q.M,

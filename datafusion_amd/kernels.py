@@ -90,7 +90,7 @@ class HipKernels:
             n_t, n_l, n_z, X, Y = self.shape
             self.ra = torch.empty((n_z, X, Y), dtype=torch.float32, device=self.device)
             self.rb = torch.empty((n_t, n_l, self.Xs, self.Ys), dtype=torch.float32, device=self.device)
-            self.zab = torch.empty((self.Xs, self.Ys), dtype=torch.float32, device=self.device)
+            self.zab = torch.empty((self.Xs, self.Ys), dtype=torch.float64, device=self.device)
 
     @staticmethod
     def _slice_bounds(cpb: int, k: int):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 107
+#define DFX_VERSION 108
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -118,13 +118,13 @@ int dfx_sweep_chunks(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float 
  * 5-D vector: `r - Ap*alpha` (fusion.py:446) becomes the small-space update below and the sweep forms r on the fly.
  *
  * dfx_resid_update:  ra = (accumulate ? ra : 0) + coef*sa*A[z,x,y] ;  rb = (accumulate ? rb : 0) + coef*sb*B[t,l,xb,yb]
- *   coef = coef_host * (coef_dev ? *coef_dev : 1);  zab = workspace of Xs*Ys floats (sum_z sum_block ra);
+ *   coef = coef_host * (coef_dev ? *coef_dev : 1);  zab = workspace of Xs*Ys doubles (sum_z sum_block ra);
  *   scal[DFX_S_RR] = ||r||^2 = nT*nL*sum ra^2 + 2*sum rb*zab + nZ*r^2*sum rb^2   (torch.dot(r, r), fusion.py:437,447)
  *   with nZ = g->nZ, the local planes: partials of z-shards add up when rb is replicated.
  * dfx_sweep_factored: dfx_sweep_chunks (modes XP, P, PINIT) with r given by its factors: x, p read + written
  *   (4N words for XP instead of 5N + the 2N of dfx_bcast). */
 int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
-                     float coef_host, const double *coef_dev, int32_t accumulate, float *zab, double *scal,
+                     float coef_host, const double *coef_dev, int32_t accumulate, double *zab, double *scal,
                      double *part, void *stream);
 int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *ra,
                        const float *rb, float *p, double *scal, float *u_part, float *v_part, double *part,
