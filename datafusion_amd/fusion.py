@@ -268,6 +268,26 @@ class FusionCG(Fusion):
         k.sqnorm_v()                                  # VV identical on every rank
         c.sum_(k.scal[cabi.S_UU:cabi.S_XP + 1])       # UU, PP, XX, XP partials
 
+    def _balance_gauge(self, du, dv, c1, c2):
+        """The split r = ra + rb is not unique: a (x/r, y/r) array g can be moved between the two (ra + g, rb - g).
+        Every update adds to the z/block-mean of ra and to the (t,l)-mean of rb in the fixed ratio w1 : w2, so a
+        start whose means are not in that ratio leaves a constant of opposite sign in ra and rb that r = ra + rb
+        has to cancel in fp32 for the rest of the solve.  Start with the means in the ratio w1 : w2: then both
+        factors shrink with r.  (Small arrays, once per solve; summed over shards.)"""
+        if not (c1 > 0 and c2 > 0):
+            return du, dv
+        r, n_z = self.spatial_increase, self.z_dim
+        xs, ys = int(self.spc.shape[-2]), int(self.spc.shape[-1])
+        a_sum = du.sum(0).reshape(xs, r, ys, r).sum((1, 3)).contiguous()      # this rank's planes
+        self.comm.sum_(a_sum)
+        a_g = a_sum * (c1 / (n_z * r * r))                                    # z/block-mean of ra
+        b_g = dv.mean((0, 1)) * c2                                            # (t,l)-mean of rb
+        w1, w2 = float(self.w1), float(self.w2)
+        shift = (a_g + b_g) * (w1 / (w1 + w2)) - a_g                          # moved from rb into ra
+        du = du + (shift / c1).repeat_interleave(r, 0).repeat_interleave(r, 1).unsqueeze(0)
+        dv = dv - shift / c2
+        return du.contiguous(), dv.contiguous()
+
     def _coefs(self):
         # A p = c1 * bcast_{t,l} u(p) + c2 * bcast_{z,block} v(p)   (fusion.py:423-426 with the 1/size
         # factors of the normalised transposes folded in)
@@ -292,6 +312,7 @@ class FusionCG(Fusion):
         du = self._cmos_loc - k.u
         dv = self.spc - k.v
         if fact:
+            du, dv = self._balance_gauge(du, dv, c1, c2)
             k.resid_update(du, dv, c1, c2, 1.0, None, False)
         else:
             k.bcast(rv, None, du, dv, None, c1, c2, 1.0, None)

@@ -386,3 +386,17 @@ def test_result_host_copy_is_exact_and_shaped():
         assert float(np.abs(a).sum()) > 0 and float(b.min()) == 1.0
     finally:
         hostcopy._CHUNK_BYTES = old
+
+
+def test_factored_residual_stays_well_conditioned():
+    """With the gauge balanced at the start (FusionCG._balance_gauge) the two factors shrink with r: after 60
+    iterations ||bcast ra||^2 + ||bcast rb||^2 is still of the order of ||r||^2 (no fp32 cancellation in ra + rb)."""
+    from datafusion_amd import FusionCG, _cabi as cabi
+    for gen, w in ((O.cells_like_inputs, {"spatial": 0.5, "spectro_temporal": 0.5}),
+                   (O.synthetic_inputs, {"spatial": 0.2, "spectro_temporal": 0.8})):
+        spc, cmos = gen(16, 8, 6, 64, 4, seed=3)
+        f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV)
+        f(60, return_numpy=False)
+        s = f.k.scal.cpu()
+        ratio = float((f.k.M * s[cabi.S_RA2] + 6 * 16 * s[cabi.S_RB2]) / s[cabi.S_RR])
+        assert 0.5 <= ratio <= 8.0, ratio

@@ -39,6 +39,9 @@ def main():
             x, _, _ = g(k, return_numpy=False)
             row[residual] = O.rel_l2(x.cpu(), ref)
             row[f"rsnew_{residual}"] = float(g.k.scal[1])
+            if residual == "factored":   # (||bcast ra||^2 + ||bcast rb||^2) / ||r||^2: 1..2 when nothing cancels
+                sc = g.k.scal.cpu()
+                row["factor_norms_over_rr"] = float((g.k.M * sc[21] + n_z * 16 * sc[22]) / sc[11])
         pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
         row["oracle_fp32_cpu"] = O.rel_l2(O.cg(pb, k, with_loss=False), ref)
         # distance moved from x0, for scale
