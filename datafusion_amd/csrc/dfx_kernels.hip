@@ -1,15 +1,16 @@
 // libdfx: gfx950 (MI355X, CDNA4) kernels for the FusionCG / FusionAdam / baseline() hot path.
 // C ABI in include/dfx.h.  Everything here is HBM-bandwidth-bound fp32 streaming + reductions:
-// no MFMA.  The 5-D vectors x, r, p (layout (t, l, z, x, y), y contiguous) are swept by
-// workgroups of four 64-lane waves; each wave owns a "wave tile" of 4 rows x 64 columns
-// (sixteen consecutive 4x4 downsampling blocks), each lane a float4 (one block row), for `zc`
-// z-planes held in registers and a chunk of `steps` consecutive (t,l) slabs:
-//   * u = sum_{t,l} (fusion.py:44-51, T and S) accumulates in zc float4 registers per lane and is
-//     written once per workgroup to u_part[chunk];
-//   * v = sum_z sum_{4x4} (fusion.py:44-51 D, fusion.py:89-98 R) is a lane-local sum over z and
-//     the float4, then two cross-lane adds (lanes l, l^16, l^32, l^48 hold the 4 rows of a block).
-// No LDS tile and no barrier in the streaming loop; LDS is only used for the per-workgroup
-// scalar partials.  r != 4 takes the generic kernels.
+// no MFMA.  The 5-D vectors x, p (and r when it is kept explicit; layout (t, l, z, x, y), y contiguous) are swept
+// by workgroups of four 64-lane waves; each wave owns a "wave tile" of consecutive r x r downsampling blocks
+// (LaneMap<R>; r = 4: 4 rows x 64 columns = sixteen 4x4 blocks), each lane a float4, for `zc` z-planes held in
+// registers, walking interleaved (t,l) slabs:
+//   * u = sum_{t,l} (fusion.py:44-51, T and S) accumulates in zc float4 registers per lane and is flushed every
+//     `steps` slabs into the workgroup's row of u_part;
+//   * v = sum_z sum_{r x r} (fusion.py:44-51 D, fusion.py:89-98 R) is a lane-local sum over z and the float4, then
+//     cross-lane adds over the lanes holding the other rows of the block (r = 4: l^16, l^32);
+//   * the CG residual is never a 5-D array by default: r = ra[z,x,y] + rb[t,l,x/r,y/r] (k_resid_*).
+// No LDS tile and no barrier in the streaming loop; LDS is only used for the per-workgroup scalar partials.
+// r outside {2, 4, 8} (or Y % 4 != 0) takes the generic kernels.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -330,7 +331,6 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
             // [c*steps*gz, (c+1)*steps*gz), so a range of chunks is a contiguous range of slabs
             const int m0 = c * a.steps * gz + bz, ms = gz;
             const int m1 = min((c + 1) * a.steps * gz, a.q.M);
-            const int chunk = c * gz + bz;
             f4 uacc[ZC];
 #pragma unroll
             for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -338,10 +338,17 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
                 sweep_steps<MODE, ZC, R, FACT, true>(a, zcnt, m0, m1, ms, off, L, fa, fb, rav, uacc, dpp, dxx, dxp);
             else
                 sweep_steps<MODE, ZC, R, FACT, false>(a, zcnt, m0, m1, ms, off, L, fa, fb, rav, uacc, dpp, dxx, dxp);
-            float *up = a.u_part + (long long)chunk * a.q.S + off;
+            // one u_part row per workgroup of the slab axis: chunk 0 writes it, later chunks add to it (same lane,
+            // same order in every run: deterministic; a sliced sweep continues the rows of the slices before it)
+            float *up = a.u_part + (long long)bz * a.q.S + off;
 #pragma unroll
-            for (int k = 0; k < ZC; ++k)
-                if (k < zcnt) st4(up + (long long)k * a.q.P, uacc[k]);
+            for (int k = 0; k < ZC; ++k) {
+                if (k < zcnt) {
+                    f4 t = uacc[k];
+                    if (c > 0) t += ld4(up + (long long)k * a.q.P);
+                    st4(up + (long long)k * a.q.P, t);
+                }
+            }
         }
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -553,10 +560,15 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
                 ddd += (double)dd;
                 dxx += (double)xx;
             }
-            float *up = a.u_part + (long long)(c * gz + bz) * a.q.S + off;
+            float *up = a.u_part + (long long)bz * a.q.S + off;
 #pragma unroll
-            for (int k = 0; k < ZC; ++k)
-                if (k < zcnt) st4(up + (long long)k * a.q.P, uacc[k]);
+            for (int k = 0; k < ZC; ++k) {
+                if (k < zcnt) {
+                    f4 t = uacc[k];
+                    if (c > 0) t += ld4(up + (long long)k * a.q.P);
+                    st4(up + (long long)k * a.q.P, t);
+                }
+            }
         }
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -1181,7 +1193,7 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         }
         long long cpb = (n_chunks + gz - 1) / gz;
         gz = (n_chunks + cpb - 1) / cpb;
-        n_chunks = cpb * gz;   // u_part rows; with interleaving the last ones may cover fewer (or no) slabs
+        n_chunks = cpb * gz;   // with interleaving the last chunks may cover fewer (or no) slabs
         out->steps = (int)steps;
         out->n_chunks = (int)n_chunks;
         out->cpb = (int)cpb;
@@ -1197,7 +1209,7 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         out->cpb = 1;
         out->n_blocks = ew_blocks(q.N, 4);
     }
-    out->u_part_elems = (long long)out->n_chunks * q.S;
+    out->u_part_elems = (long long)(out->n_chunks / out->cpb) * q.S;   // one row per workgroup of the slab axis
     out->v_part_elems = (long long)out->n_zchunks * q.M * q.Ps;
     long long rows = (long long)out->n_blocks * DFX_MAX_SLICES;
     if (rows < DFX_EW_MAXBLOCKS) rows = DFX_EW_MAXBLOCKS;
@@ -1391,7 +1403,7 @@ int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, flo
     if (!u_part || !u || !scal || !part) return fail(DFX_EINVAL, "dfx_reduce_u: NULL buffer");
     hipStream_t st = (hipStream_t)stream;
     const int nb = ew_blocks(q.S, 1);
-    hipLaunchKernelGGL(k_reduce_u, dim3(nb), dim3(256), 0, st, u_part, u, q.S, pl->n_chunks, part);
+    hipLaunchKernelGGL(k_reduce_u, dim3(nb), dim3(256), 0, st, u_part, u, q.S, pl->n_chunks / pl->cpb, part);
     DFX_LAUNCH_CHECK("dfx_reduce_u");
     return fold(part, nb, 1, scal + DFX_S_UU, 1.0, st);
 }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 108
+#define DFX_VERSION 109
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -48,7 +48,7 @@ typedef struct dfx_plan {
     int32_t cpb;         /* consecutive chunks one workgroup walks through */
     int32_t n_blocks;    /* workgroups per sweep / bcast launch */
     int32_t pad_;
-    int64_t u_part_elems;    /* floats: n_chunks * nZ*X*Y */
+    int64_t u_part_elems;    /* floats: (n_chunks / cpb) * nZ*X*Y: one row per workgroup of the slab axis */
     int64_t v_part_elems;    /* floats: n_zchunks * nT*nL*Xs*Ys */
     int64_t part_elems;      /* doubles: max(n_blocks * DFX_MAX_SLICES, DFX_EW_MAXBLOCKS) * DFX_NPART */
 } dfx_plan;
@@ -99,7 +99,7 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc, int32
  * called from the closure A fusion.py:423-426; the axpy `x + p*alpha` fusion.py:445; the
  * direction update fusion.py:455; the dot products / norms of fusion.py:250-251,444).
  * alpha, beta are read from scal[DFX_S_ALPHA], scal[DFX_S_BETA] on the device.
- * Outputs: u_part [n_chunks][nZ][X][Y], v_part [n_zchunks][nT*nL][Xs][Ys], scal[PP, XX, XP]. */
+ * Outputs: u_part [n_chunks/cpb][nZ][X][Y], v_part [n_zchunks][nT*nL][Xs][Ys], scal[PP, XX, XP]. */
 int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
               double *scal, float *u_part, float *v_part, double *part, void *stream);
 
@@ -151,7 +151,7 @@ int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, fl
                   const float *B, const float *mask, double lr, double beta1, double beta2, double eps, int32_t step,
                   int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream);
 
-/* u[i] = sum_c u_part[c][i] (i < nZ*X*Y); scal[DFX_S_UU] = sum u^2. */
+/* u[i] = sum over the n_chunks/cpb rows of u_part[row][i] (i < nZ*X*Y); scal[DFX_S_UU] = sum u^2. */
 int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,
                  double *part, void *stream);
 /* v[m] = sum_zc v_part[zc][m] for the slabs m_lo <= m < m_hi (rows of Xs*Ys floats). */

@@ -114,7 +114,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libdfx.so does not export {n}"
-    assert cabi.lib().dfx_version() == 108
+    assert cabi.lib().dfx_version() == 109
 
 
 def test_header_constants_match_python_mirror():
@@ -147,7 +147,7 @@ def test_planner_covers_geometry(dims, fast):
         assert (p.n_zchunks - 1) * p.zc < n_z
     else:
         assert p.n_chunks == 1 and p.n_zchunks == 1
-    assert p.u_part_elems == p.n_chunks * n_z * X * Y
+    assert p.u_part_elems == (p.n_chunks // max(p.cpb, 1)) * n_z * X * Y
     assert p.v_part_elems == p.n_zchunks * n_t * n_l * (X // r) * (Y // r)
     assert p.part_elems >= max(p.n_blocks, cabi.EW_MAXBLOCKS) * cabi.NPART
     if fast:
