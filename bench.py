@@ -32,6 +32,8 @@ WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "c3g8": (512, 32, 4, 256, 4),        # config 3 as sharded over 8 GPUs (per-GPU slab)
     "c4g8": (256, 16, 4, 512, 4),        # config 4 as sharded over 8 GPUs (per-GPU slab)
     "cells": (64, 16, 20, 128, 4),       # README-like
+    "c2r2": (256, 16, 16, 128, 2),       # C2 volume with spatial_increase 2 / 8 (LaneMap<2>, LaneMap<8>)
+    "c2r8": (256, 16, 16, 128, 8),
     "tiny": (8, 4, 4, 64, 4),
 }
 
