@@ -61,6 +61,7 @@ SIGNATURES = {
     "dfx_scale": [_P, _i64, _P, _i64, _f, _P, _P],
     "dfx_sum": [_P, _i64, _P, _P, _P],
     "dfx_recip": [_P, _P, _d, _P],
+    "dfx_diff_scale": [_P, _P, _P, _P, _i64, _i64, _f, _P],
     "dfx_sum_axis": [_P, _P, _i64, _i64, _i64, _P],
     "dfx_expand_axis": [_P, _P, _i64, _i64, _i64, _f, _P],
     "dfx_block_sum": [_P, _P, _i64, _i64, _i64, _i32, _P],

@@ -926,6 +926,18 @@ __global__ __launch_bounds__(256) void k_scale(float *y, long long n, const floa
     }
 }
 
+// out = coef * (a - b) * mask: the small-space residuals cmos_n - u(x), spc_n - v(x) behind r0 (fusion.py:428-435),
+// the loss gradient (autograd of fusion.py:216-232) and its masked variants
+__global__ __launch_bounds__(256) void k_diff_scale(float *out, const float *a, const float *b, const float *mask,
+                                                    long long mask_n, long long n, float coef) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = coef * (a[i] - b[i]);
+        if (mask) v *= mask[i % mask_n];   // a (x/r, y/r) mask repeats over (t, l)
+        out[i] = v;
+    }
+}
+
 // out[a][b] = sum_{k < R} x[(a*R + k)*B + b]: the marginals a caller takes right after a solve
 // (x.sum(axis=0) -> A=1,R=nT ; x.sum(axis=1) -> A=nT,R=nL ; cells.ipynb cell 27bf9830e81df430), one read of x.
 __global__ __launch_bounds__(256) void k_sum_axis(const float *x, float *out, long long A, long long R, long long B) {
@@ -1491,6 +1503,16 @@ int dfx_scale(float *y, int64_t n, const float *mask, int64_t mask_n, float coef
     hipLaunchKernelGGL(k_scale, dim3(ew_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, y, (long long)n, mask,
                        (long long)(mask ? mask_n : 1), coef_host, coef_dev);
     DFX_LAUNCH_CHECK("dfx_scale");
+    return 0;
+}
+
+int dfx_diff_scale(float *out, const float *a, const float *b, const float *mask, int64_t mask_n, int64_t n,
+                   float coef, void *stream) {
+    if (!out || !a || !b || n <= 0 || (mask && (mask_n <= 0 || n % mask_n)))
+        return fail(DFX_EINVAL, "dfx_diff_scale: bad argument");
+    hipLaunchKernelGGL(k_diff_scale, dim3(ew_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, out, a, b, mask,
+                       (long long)(mask ? mask_n : 1), (long long)n, coef);
+    DFX_LAUNCH_CHECK("dfx_diff_scale");
     return 0;
 }
 

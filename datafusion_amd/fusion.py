@@ -309,8 +309,8 @@ class FusionCG(Fusion):
         x, rv, pv = self.x, self._r, self._p
         # r0 = c1 bcast(cmos_n - u(x0)) + c2 bcast(spc_n - v(x0))
         self._project(x)
-        du = self._cmos_loc - k.u
-        dv = self.spc - k.v
+        du = k.diff_scale(self._cmos_loc, k.u, None, 1.0)
+        dv = k.diff_scale(self.spc, k.v, None, 1.0)
         if fact:
             du, dv = self._balance_gauge(du, dv, c1, c2)
             k.resid_update(du, dv, c1, c2, 1.0, None, False)
@@ -390,11 +390,8 @@ class _FusionLossFn(torch.autograd.Function):
     def forward(ctx, x, fusion, mask_grad):
         fusion._project(x.detach())
         k = fusion.k
-        du = fusion._cmos_loc - k.u
-        dv = fusion.spc - k.v
-        if fusion.mask_noise:
-            du = du * fusion._cmask_loc
-            dv = dv * fusion._smask_f
+        du = k.diff_scale(fusion._cmos_loc, k.u, fusion._cmask_loc if fusion.mask_noise else None, 1.0)
+        dv = k.diff_scale(fusion.spc, k.v, fusion._smask_f if fusion.mask_noise else None, 1.0)
         ctx.fusion, ctx.mask_grad = fusion, mask_grad
         ctx.save_for_backward(du, dv)
         l1, l2 = fusion._losses_from_uv()
@@ -456,13 +453,10 @@ class FusionAdam(Fusion):
             self.curr_iter += 1
             l1, l2 = self._losses_from_uv()                                     # fusion.py:332
             # d loss / d u and d loss / d v (autograd of fusion.py:216-232), small arrays
-            A = (-2.0 * w1) * (self._cmos_loc - k.u)
-            B = (-2.0 * w2) * (self.spc - k.v)
-            if self.mask_noise:
-                A = A * self._cmask_loc
-                B = B * self._smask_f
+            A = k.diff_scale(self._cmos_loc, k.u, self._cmask_loc if self.mask_noise else None, -2.0 * w1)
+            B = k.diff_scale(self.spc, k.v, self._smask_f if self.mask_noise else None, -2.0 * w2)
             self._adam_step += 1
-            k.adam_step(x, self._m1, self._m2, A.contiguous(), B.contiguous(),
+            k.adam_step(x, self._m1, self._m2, A, B,
                         self._cmask_loc if self.mask_noise else None,                  # fusion.py:274-278
                         lr, self.betas[0], self.betas[1], self.adam_eps, self._adam_step, non_neg)
             c.sum_(k.v)

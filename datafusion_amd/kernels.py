@@ -221,6 +221,17 @@ class HipKernels:
                                       self._stream()), "dfx_scale")
 
     @_on_device
+    def diff_scale(self, a, b, mask, coef: float):
+        """coef * (a - b) * mask as a new small tensor shaped like a (mask may cover the trailing axes only)."""
+        self._chk(a, b, mask)
+        assert a.numel() == b.numel() and (mask is None or a.numel() % mask.numel() == 0)
+        out = torch.empty_like(a)
+        cabi.check(self.lib.dfx_diff_scale(cabi.ptr(out), cabi.ptr(a), cabi.ptr(b), cabi.ptr(mask),
+                                           0 if mask is None else mask.numel(), a.numel(), coef, self._stream()),
+                   "dfx_diff_scale")
+        return out
+
+    @_on_device
     def sum(self, y) -> None:
         """SUM = sum(y)."""
         self._chk(y)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 109
+#define DFX_VERSION 110
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -183,6 +183,12 @@ int dfx_scale(float *y, int64_t n, const float *mask, int64_t mask_n, float coef
               const double *coef_dev, void *stream);
 /* scal[DFX_S_SUM] = sum_i y[i]  (fusion.py:209 tensor.sum()). */
 int dfx_sum(const float *y, int64_t n, double *scal, double *part, void *stream);
+/* out[i] = coef * (a[i] - b[i]) * (mask ? mask[i % mask_n] : 1), i < n: the small-space differences cmos_n - u(x) and
+ * spc_n - v(x) of b - A(x0) (fusion.py:428-435) and of the loss gradient (autograd of fusion.py:216-232, with the
+ * masks of fusion.py:218-223). */
+int dfx_diff_scale(float *out, const float *a, const float *b, const float *mask, int64_t mask_n, int64_t n,
+                   float coef, void *stream);
+
 /* out[a][b] = sum_{k<R} x[(a*R + k)*B + b]  (x viewed as (A, R, B)): the marginals callers take right after a
  * solve - x.sum(axis=0): A=1, R=nT; x.sum(axis=1): A=nT, R=nL (analysis/cells.ipynb cell 27bf9830e81df430) -
  * computed on the device so the 5-D volume need not cross PCIe (fusion.py:489-493 returns it whole). */

@@ -44,6 +44,10 @@ class CpuStandIn:
         self.scal[cabi.S_RR] = (self._resid5().double() ** 2).sum()   # the plain 5-D norm (the HIP side uses the
                                                                        # small-space identity: cross-checks it)
 
+    def diff_scale(self, a, b, mask, coef):
+        out = torch.tensor(coef, dtype=torch.float32) * (a - b)
+        return out * mask if mask is not None else out
+
     def new_vector(self):
         return torch.empty(self.shape)
 

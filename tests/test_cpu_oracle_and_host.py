@@ -114,7 +114,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libdfx.so does not export {n}"
-    assert cabi.lib().dfx_version() == 109
+    assert cabi.lib().dfx_version() == 110
 
 
 def test_header_constants_match_python_mirror():

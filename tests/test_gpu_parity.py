@@ -331,6 +331,10 @@ def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     assert O.rel_l2(m24.cpu(), e2.cpu()) <= 1e-6
     u4, v4 = proj(x4.double())
     assert O.rel_l2(k.u.cpu(), u4.cpu()) <= 1e-6 and O.rel_l2(k.v.cpu(), v4.cpu()) <= 1e-6
+    # small-space difference kernel
+    a2, b2 = torch.randn(n_z, X, Y, device=DEV), torch.randn(n_z, X, Y, device=DEV)
+    assert torch.equal(k.diff_scale(a2, b2, mask, -0.6), (torch.tensor(-0.6) * (a2 - b2)) * mask)
+    assert torch.equal(k.diff_scale(a2, b2, None, 1.0), a2 - b2)
     # axis sums
     assert O.rel_l2(k.sum_axis(x, 0).cpu(), xd.sum(0).cpu()) <= 1e-6
     assert O.rel_l2(k.sum_axis(x, 1).cpu(), xd.sum(1).cpu()) <= 1e-6
