@@ -14,7 +14,11 @@ Differences from the reference a caller can observe (documented, deliberate):
   * loss() is not evaluated every CG iteration unless verbose=True (fusion.py:458 computes it
     only to feed the progress bar; it does not influence x);
   * `group=` (a torch.distributed process group) z-shards the volume: every rank passes the full
-    (small) spc and cmos, owns planes z_range of x, and gets its own shard back.
+    (small) spc and cmos, owns planes z_range of x, and gets its own shard back;
+  * FusionCG keeps the residual r = b - A x as its two small-space factors by default
+    (`residual="factored"`; `"explicit"` stores it as a third 5-D vector, the literal fusion.py:446): same
+    recurrence, same numbers, one 5-D pass per iteration instead of two;
+  * return_numpy=True copies x to the host through pinned bounce buffers (hostcopy.py): same array, ~8x sooner.
 """
 from __future__ import annotations
 
