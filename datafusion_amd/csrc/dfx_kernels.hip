@@ -248,8 +248,11 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
             f4 xv[ZB], rv[ZB], pv[ZB];
 #pragma unroll
             for (int j = 0; j < ZB; ++j) {
-                if (FULL || g + j < zcnt) {
-                    const long long i = base + (long long)(g + j) * a.q.P;
+                {
+                    // a ragged last z-chunk re-reads its last plane instead of branching around the loads (the
+                    // branches made the compiler wait for every load separately); stores and sums stay predicated
+                    const int kk = FULL ? g + j : min(g + j, zcnt - 1);
+                    const long long i = base + (long long)kk * a.q.P;
                     if (MODE == DFX_SWEEP_PROJECT) {
                         xv[j] = ld4s(a.x + i);
                     } else if (MODE == DFX_SWEEP_XP) {
@@ -389,8 +392,8 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0
                 if (HAS_IN) {
                     const long long base = (long long)mm * a.q.S + off;
 #pragma unroll
-                    for (int k = 0; k < ZC; ++k)
-                        if (FULL || k < zcnt) iv[u][k] = ld4s(a.in + base + (long long)k * a.q.P);
+                    for (int k = 0; k < ZC; ++k)   // ragged chunk: re-read the last plane rather than branch (see sweep_steps)
+                        iv[u][k] = ld4s(a.in + base + (long long)(FULL ? k : min(k, zcnt - 1)) * a.q.P);
                 }
             }
         }
@@ -530,8 +533,8 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
                     f4 xv[ZB], e1[ZB], e2[ZB];
 #pragma unroll
                     for (int j = 0; j < ZB; ++j) {
-                        if (g0 + j < zcnt) {
-                            const long long i = base + (long long)(g0 + j) * a.q.P;
+                        {   // ragged chunk: re-read the last plane rather than branch (see sweep_steps)
+                            const long long i = base + (long long)min(g0 + j, zcnt - 1) * a.q.P;
                             xv[j] = ld4s(a.x + i);
                             e1[j] = ld4s(a.m1 + i);
                             e2[j] = ld4s(a.m2 + i);
@@ -1166,9 +1169,13 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         int zc;
         // measured on MI355X at t256 x l16 x z16 x 128^2 (tools/tune_kernels.py): zc = 8 beats 16 (which
         // needs 256 VGPRs + AGPRs, and spills in the Adam kernel) by 5 % and 4 by 3 %: 16 is not built
-        if (q.nZ % 8 == 0) zc = 8;
-        else if (q.nZ % 4 == 0 || q.nZ < 8) zc = 4;
-        else zc = 8;
+        // the slowest workgroups are those of the full z-chunks, so a ragged nZ costs its padded plane count:
+        // take the chunk size that pads least, 8 on a tie (nZ = 5..7 -> one chunk of 8; 10 -> 4 + 4 + 2; measured at
+        // t256 x l16 x z{5,6,10} x 128^2: sweep 1.29 vs 1.44, 1.41 vs 1.53, 2.48 vs 2.66 ms)
+        {
+            const int pad8 = (q.nZ + 7) / 8 * 8, pad4 = (q.nZ + 3) / 4 * 4;
+            zc = pad8 <= pad4 ? 8 : 4;
+        }
         if (zc_req) {
             if (zc_req != 4 && zc_req != 8) return fail(DFX_EINVAL, "zc must be 0 (auto), 4 or 8");
             zc = zc_req;
