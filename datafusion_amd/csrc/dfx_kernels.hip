@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
 }
 
 // ------------------------------------------------------------------------------------------
-// Fast broadcast-axpy: out = in + coef*mask*(sa*A[z,x,y] + sb*B[m,x/4,y/4]); sum(out^2)
+// Fast broadcast-axpy: out = in + coef*mask*(sa*A[z,x,y] + sb*B[m,x/r,y/r]); sum(out^2)
 // ------------------------------------------------------------------------------------------
 struct BcastArgs {
     float *out;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(con
 
 // ------------------------------------------------------------------------------------------
 // Fused Adam step (fusion.py:324-346 with torch.optim.Adam(amsgrad=False, weight_decay=0)):
-//   g = mask * (A[z,x,y] + B[m,x/4,y/4])        gradient, broadcast on read: never stored in HBM
+//   g = mask * (A[z,x,y] + B[m,x/r,y/r])        gradient, broadcast on read: never stored in HBM
 //   m1 += (1-b1)(g - m1) ; m2 = b2 m2 + (1-b2) g^2
 //   x -= (lr/bc1) * m1 / (sqrt(m2)/sqrt(bc2) + eps) ; optional clamp(min=0)
 // plus, in the same pass, what the next iteration needs: u(x), v(x), ||dx||^2, ||x||^2.
