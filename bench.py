@@ -76,7 +76,7 @@ def bench_adam(a, world, rank, dev, group, use_dist):
     n_t, n_l, nz_gpu, xy, r = WORKLOADS[a.workload]
     spc, cmos = synthetic(n_t, n_l, nz_gpu * world, xy, r)
     f = FusionAdam(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
-                   device=dev, group=group, fused=(a.method == "adam"))
+                   device=dev, group=group, fused=(a.method == "adam"), moment1=a.moment1)
     n_local = f.k.N
     f(lr=1e-8, max_iterations=a.warmup, return_numpy=False)
     f.k.timing = {}
@@ -98,10 +98,13 @@ def bench_adam(a, world, rank, dev, group, use_dist):
            "config": {"workload": f"FusionAdam ({a.method}) t{n_t} x l{n_l} x z{nz_gpu * world} x {xy} x {xy}, r={r}, lr=1e-8",
                       "n_elements": n_local * world}, "kernel_ms": kern}
     if a.method == "adam":
-        ach = 24.0 * n_local / (kern["adam"] * 1e-3) / 1e9      # x, m1, m2 read + written
-        out["roofline"] = {"bound": "hbm", "kernel": f"k_adam_fast<{f.k.plan.zc}>", "achieved": ach,
+        fact = a.moment1 == "factored"
+        name, words = ("adamf", 4) if fact else ("adam", 6)       # x, m2 (and m1) read + written
+        ach = 4.0 * words * n_local / (kern[name] * 1e-3) / 1e9
+        out["config"]["moment1"] = a.moment1
+        out["roofline"] = {"bound": "hbm", "kernel": f"k_adam_fast<{f.k.plan.zc},{a.moment1} m1>", "achieved": ach,
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                           "bytes_per_launch": 24 * n_local, "avg_launch_ms": kern["adam"]}
+                           "bytes_per_launch": 4 * words * n_local, "avg_launch_ms": kern[name]}
     if rank == 0:
         emit(out)
     if use_dist:
@@ -134,6 +137,8 @@ def main():
     ap.add_argument("--residual", default="factored", choices=["factored", "explicit"],
                     help="factored (default): r kept as its two small-space factors, 4N words/iter | explicit: r is a "
                          "third 5-D vector, 7N words/iter")
+    ap.add_argument("--moment1", default="factored", choices=["factored", "explicit"],
+                    help="--method adam: first moment as two small-space factors (4N words/iter) or a 5-D vector (6N)")
     ap.add_argument("--single", action="store_true", help="time only --residual, not the other representation as well")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--target-blocks", type=int, default=0)

@@ -460,9 +460,15 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(con
 //   x -= (lr/bc1) * m1 / (sqrt(m2)/sqrt(bc2) + eps) ; optional clamp(min=0)
 // plus, in the same pass, what the next iteration needs: u(x), v(x), ||dx||^2, ||x||^2.
 // x, m1, m2 read + written: 6N words per iteration.
+//
+// Factored first moment (M1F).  m1 is linear in the gradients, and every gradient is mask * (A (+) B): so
+//   m1 = mask * (m1a[z,x,y] + m1b[m,x/r,y/r]),  m1a <- lerp(m1a, A, 1-b1),  m1b <- lerp(m1b, B, 1-b1)   (dfx_lerp)
+// exactly, and the 5-D m1 array need not exist: x and m2 read + written, 4N words per iteration.  (m2 is an average of
+// g^2 = A^2 + 2AB + B^2; the cross terms do not factor.)
 // ------------------------------------------------------------------------------------------
 struct AdamArgs {
     float *x, *m1, *m2;
+    const float *m1a, *m1b;   // M1F: the first moment AFTER this step's lerp, as its two small-space factors
     const float *A, *B, *mask;
     float *u_part, *v_part;
     double *part;
@@ -472,8 +478,9 @@ struct AdamArgs {
     int steps, cpb;
 };
 
+template <bool M1F>
 __device__ __forceinline__ float adam_elem(float x, float g, float &m1, float &m2, const AdamArgs &a) {
-    m1 = m1 + a.omb1 * (g - m1);                          // exp_avg.lerp_(grad, 1 - beta1)
+    if (!M1F) m1 = m1 + a.omb1 * (g - m1);                // exp_avg.lerp_(grad, 1 - beta1); M1F: m1 is already new
     m2 = a.b2 * m2 + a.omb2 * (g * g);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = __fsqrt_rn(m2) * a.inv_sqrt_bc2 + a.eps;
     float xn = x - a.step_size * __fdiv_rn(m1, denom);    // param.addcdiv_(exp_avg, denom, value=-step_size)
@@ -481,20 +488,80 @@ __device__ __forceinline__ float adam_elem(float x, float g, float &m1, float &m
     return xn;
 }
 
+template <bool M1F>
 __device__ __forceinline__ f4 adam_elem4(f4 x, f4 g, f4 &m1, f4 &m2, const AdamArgs &a) {
     float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
     float p0 = m1.x, p1 = m1.y, p2 = m1.z, p3 = m1.w;
     float q0 = m2.x, q1 = m2.y, q2 = m2.z, q3 = m2.w;
-    x0 = adam_elem(x0, g.x, p0, q0, a);
-    x1 = adam_elem(x1, g.y, p1, q1, a);
-    x2 = adam_elem(x2, g.z, p2, q2, a);
-    x3 = adam_elem(x3, g.w, p3, q3, a);
+    x0 = adam_elem<M1F>(x0, g.x, p0, q0, a);
+    x1 = adam_elem<M1F>(x1, g.y, p1, q1, a);
+    x2 = adam_elem<M1F>(x2, g.z, p2, q2, a);
+    x3 = adam_elem<M1F>(x3, g.w, p3, q3, a);
     m1 = (f4){p0, p1, p2, p3};
     m2 = (f4){q0, q1, q2, q3};
     return (f4){x0, x1, x2, x3};
 }
 
-template <int ZC, int R, bool HAS_MASK>
+// One slab's worth of a lane's operands.  The kernel keeps two: the loads of slab m + gz are issued before the
+// arithmetic of slab m starts.  With the factored first moment the pass moves 4N words and the sqrt + division per
+// element (~1.2 ms of VALU time at C2) is no longer hidden behind memory time by a single resident wave per SIMD.
+template <int ZC>
+struct AdamSlab {
+    f4 x[ZC], e1[ZC], e2[ZC];
+    f4 b, mb;
+};
+
+template <int ZC, int R, bool M1F>
+__device__ __forceinline__ void adam_load(const AdamArgs &a, AdamSlab<ZC> &s, const LaneMap<R> &L, int m,
+                                          long long off, int zcnt) {
+    const long long base = (long long)m * a.q.S + off;
+    s.b = L.bload(a.B + (long long)m * a.q.Ps);
+    s.mb = (f4){0.f, 0.f, 0.f, 0.f};
+    if (M1F) s.mb = L.bload(a.m1b + (long long)m * a.q.Ps);
+#pragma unroll
+    for (int k = 0; k < ZC; ++k) {   // ragged chunk: re-read the last plane rather than branch (see sweep_steps)
+        const long long i = base + (long long)min(k, zcnt - 1) * a.q.P;
+        s.x[k] = ld4s(a.x + i);
+        if (!M1F) s.e1[k] = ld4s(a.m1 + i);
+        s.e2[k] = ld4s(a.m2 + i);
+    }
+}
+
+template <int ZC, int R, bool HAS_MASK, bool M1F>
+__device__ __forceinline__ void adam_apply(const AdamArgs &a, AdamSlab<ZC> &s, const LaneMap<R> &L, int m,
+                                           long long off, int zcnt, const f4 (&av)[ZC], const f4 (&mk)[ZC],
+                                           const f4 (&m1av)[ZC], f4 (&uacc)[ZC], float *vbase, int lane, double &ddd,
+                                           double &dxx) {
+    const long long base = (long long)m * a.q.S + off;
+    f4 s4 = {0.f, 0.f, 0.f, 0.f};
+    float dd = 0.f, xx = 0.f;
+#pragma unroll
+    for (int k = 0; k < ZC; ++k) {
+        if (k < zcnt) {
+            const long long i = base + (long long)k * a.q.P;
+            f4 g = av[k] + s.b;
+            if (HAS_MASK) g *= mk[k];
+            if (M1F) {
+                s.e1[k] = m1av[k] + s.mb;
+                if (HAS_MASK) s.e1[k] *= mk[k];
+            }
+            const f4 xn = adam_elem4<M1F>(s.x[k], g, s.e1[k], s.e2[k], a);
+            st4s(a.x + i, xn);
+            if (!M1F) st4s(a.m1 + i, s.e1[k]);
+            st4s(a.m2 + i, s.e2[k]);
+            const f4 d = xn - s.x[k];
+            dd += dot4(d, d);
+            xx += dot4(xn, xn);
+            uacc[k] += xn;
+            s4 += xn;
+        }
+    }
+    L.vstore(s4, vbase + (long long)m * a.q.Ps, lane);
+    ddd += (double)dd;
+    dxx += (double)xx;
+}
+
+template <int ZC, int R, bool HAS_MASK, bool M1F>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(const AdamArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
@@ -506,14 +573,16 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
     if (L.act) {
         const long long off = (long long)z0 * a.q.P + L.off2;
         float *vbase = a.v_part + (long long)blockIdx.y * a.q.M * a.q.Ps;
-        f4 av[ZC], mk[ZC];
+        f4 av[ZC], mk[ZC], m1av[ZC];
 #pragma unroll
         for (int k = 0; k < ZC; ++k) {
             av[k] = (f4){0.f, 0.f, 0.f, 0.f};
             mk[k] = (f4){1.f, 1.f, 1.f, 1.f};
+            m1av[k] = (f4){0.f, 0.f, 0.f, 0.f};
             if (k < zcnt) {
                 av[k] = ld4(a.A + off + (long long)k * a.q.P);
                 if (HAS_MASK) mk[k] = ld4(a.mask + off + (long long)k * a.q.P);
+                if (M1F) m1av[k] = ld4(a.m1a + off + (long long)k * a.q.P);
             }
         }
         for (int c = 0; c < a.cpb; ++c) {
@@ -522,46 +591,18 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
             f4 uacc[ZC];
 #pragma unroll
             for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
-            for (int m = m0; m < m1e; m += gz) {
-                const long long base = (long long)m * a.q.S + off;
-                const f4 b = L.bload(a.B + (long long)m * a.q.Ps);
-                f4 s4 = {0.f, 0.f, 0.f, 0.f};
-                float dd = 0.f, xx = 0.f;
-                constexpr int ZB = ZC < DFX_ADAM_ZB ? ZC : DFX_ADAM_ZB;   // planes loaded, updated, stored together
-#pragma unroll
-                for (int g0 = 0; g0 < ZC; g0 += ZB) {
-                    f4 xv[ZB], e1[ZB], e2[ZB];
-#pragma unroll
-                    for (int j = 0; j < ZB; ++j) {
-                        {   // ragged chunk: re-read the last plane rather than branch (see sweep_steps)
-                            const long long i = base + (long long)min(g0 + j, zcnt - 1) * a.q.P;
-                            xv[j] = ld4s(a.x + i);
-                            e1[j] = ld4s(a.m1 + i);
-                            e2[j] = ld4s(a.m2 + i);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < ZB; ++j) {
-                        const int k = g0 + j;
-                        if (k < zcnt) {
-                            const long long i = base + (long long)k * a.q.P;
-                            f4 g = av[k] + b;
-                            if (HAS_MASK) g *= mk[k];
-                            const f4 xn = adam_elem4(xv[j], g, e1[j], e2[j], a);
-                            st4s(a.x + i, xn);
-                            st4s(a.m1 + i, e1[j]);
-                            st4s(a.m2 + i, e2[j]);
-                            const f4 d = xn - xv[j];
-                            dd += dot4(d, d);
-                            xx += dot4(xn, xn);
-                            uacc[k] += xn;
-                            s4 += xn;
-                        }
-                    }
+            AdamSlab<ZC> sa, sb;   // ping-pong: one being updated, the other in flight
+            int m = m0;
+            if (m < m1e) adam_load<ZC, R, M1F>(a, sa, L, m, off, zcnt);
+            while (m < m1e) {
+                const int mb = m + gz, ma = mb + gz;
+                if (mb < m1e) adam_load<ZC, R, M1F>(a, sb, L, mb, off, zcnt);
+                adam_apply<ZC, R, HAS_MASK, M1F>(a, sa, L, m, off, zcnt, av, mk, m1av, uacc, vbase, lane, ddd, dxx);
+                if (mb < m1e) {
+                    if (ma < m1e) adam_load<ZC, R, M1F>(a, sa, L, ma, off, zcnt);
+                    adam_apply<ZC, R, HAS_MASK, M1F>(a, sb, L, mb, off, zcnt, av, mk, m1av, uacc, vbase, lane, ddd, dxx);
                 }
-                L.vstore(s4, vbase + (long long)m * a.q.Ps, lane);
-                ddd += (double)dd;
-                dxx += (double)xx;
+                m = ma;
             }
             float *up = a.u_part + (long long)bz * a.q.S + off;
 #pragma unroll
@@ -586,13 +627,21 @@ __global__ __launch_bounds__(256) void k_gen_adam(AdamArgs a) {
         const int j = (int)(i - m * a.q.S);
         const int xy = (int)(j % a.q.P);
         const int xi = xy / a.q.Y, yi = xy - xi * a.q.Y;
-        float g = a.A[j] + a.B[m * a.q.Ps + (long long)(xi / a.q.r) * a.q.Ys + yi / a.q.r];
+        const long long jb = m * a.q.Ps + (long long)(xi / a.q.r) * a.q.Ys + yi / a.q.r;
+        float g = a.A[j] + a.B[jb];
         if (a.mask) g *= a.mask[j];
         const float xo = a.x[i];
-        float e1 = a.m1[i], e2 = a.m2[i];
-        const float xn = adam_elem(xo, g, e1, e2, a);
+        float e1, e2 = a.m2[i], xn;
+        if (a.m1) {
+            e1 = a.m1[i];
+            xn = adam_elem<false>(xo, g, e1, e2, a);
+            a.m1[i] = e1;
+        } else {
+            e1 = a.m1a[j] + a.m1b[jb];
+            if (a.mask) e1 *= a.mask[j];
+            xn = adam_elem<true>(xo, g, e1, e2, a);
+        }
         a.x[i] = xn;
-        a.m1[i] = e1;
         a.m2[i] = e2;
         ddd += (double)((xn - xo) * (xn - xo));
         dxx += (double)(xn * xn);
@@ -938,6 +987,15 @@ __global__ __launch_bounds__(256) void k_diff_scale(float *out, const float *a, 
         float v = coef * (a[i] - b[i]);
         if (mask) v *= mask[i % mask_n];   // a (x/r, y/r) mask repeats over (t, l)
         out[i] = v;
+    }
+}
+
+// m += w * (g - m): torch's exp_avg.lerp_(grad, w) on the small-space factors of the first Adam moment
+__global__ __launch_bounds__(256) void k_lerp(float *m, const float *g, long long n, float w) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = m[i];
+        m[i] = v + w * (g[i] - v);
     }
 }
 
@@ -1373,32 +1431,40 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
     return fold(part, n_rows, 1, scal + DFX_S_RR, 1.0, st);
 }
 
-int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, float *m2, const float *A,
-                  const float *B, const float *mask, double lr, double beta1, double beta2, double eps, int32_t step,
-                  int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream) {
+static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, const float *m1a, const float *m1b,
+                     float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
+                     double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
+                     float *v_part, double *part, void *stream) {
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
-    if (!x || !m1 || !m2 || !A || !B || !scal || !u_part || !v_part || !part)
+    const bool m1f = (m1 == nullptr);
+    if (!x || !m2 || !A || !B || !scal || !u_part || !v_part || !part || (m1f && (!m1a || !m1b)))
         return fail(DFX_EINVAL, "dfx_adam_step: NULL buffer");
     if (step < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1))
         return fail(DFX_EINVAL, "dfx_adam_step: step >= 1 and betas in [0, 1) required");
     hipStream_t st = (hipStream_t)stream;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    AdamArgs a{x, m1, m2, A, B, mask, u_part, v_part, part, (float)beta1, (float)beta2, (float)(1.0 - beta1),
-               (float)(1.0 - beta2), (float)eps,
+    AdamArgs a{x, m1, m2, m1a, m1b, A, B, mask, u_part, v_part, part, (float)beta1, (float)beta2,
+               (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), non_neg ? 1 : 0, q, pl->steps, pl->cpb};
     int n_rows;
     if (pl->fast) {
-        if (!aligned16(x) || !aligned16(m1) || !aligned16(m2) || !aligned16(A) || !aligned16(mask) || !aligned16(u_part))
-            return fail(DFX_EALIGN, "dfx_adam_step: x, m1, m2, A, mask, u_part must be 16-byte aligned");
+        if (!aligned16(x) || !aligned16(m1) || !aligned16(m2) || !aligned16(A) || !aligned16(mask) ||
+            !aligned16(u_part) || !aligned16(m1a))
+            return fail(DFX_EALIGN, "dfx_adam_step: x, m1 (m1a), m2, A, mask, u_part must be 16-byte aligned");
+        if (!aligned8(B) || !aligned8(v_part) || !aligned8(m1b))
+            return fail(DFX_EALIGN, "dfx_adam_step: B, m1b, v_part must be 8-byte aligned");
         dim3 grid((q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb),
             block(64 * DFX_WAVES);
-        if (!aligned8(B) || !aligned8(v_part)) return fail(DFX_EALIGN, "dfx_adam_step: B, v_part must be 8-byte aligned");
-        if (mask)
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, true>), grid, block, 0, st, a));
+        if (mask && m1f)
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, true, true>), grid, block, 0, st, a));
+        else if (mask)
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, true, false>), grid, block, 0, st, a));
+        else if (m1f)
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false, true>), grid, block, 0, st, a));
         else
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false>), grid, block, 0, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false, false>), grid, block, 0, st, a));
         DFX_LAUNCH_CHECK("dfx_adam_step(fast)");
         n_rows = pl->n_blocks;
     } else {
@@ -1412,6 +1478,31 @@ int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, fl
         DFX_LAUNCH_CHECK("dfx_adam_step(generic v)");
     }
     return fold(part, n_rows, 2, scal + DFX_S_ADAM_DD, 1.0, st);   // (DD, XX) -> consecutive slots
+}
+
+int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, float *m2, const float *A,
+                  const float *B, const float *mask, double lr, double beta1, double beta2, double eps, int32_t step,
+                  int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream) {
+    if (!m1) return fail(DFX_EINVAL, "dfx_adam_step: NULL buffer");
+    return adam_impl(g, pl, x, m1, nullptr, nullptr, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, scal, u_part,
+                     v_part, part, stream);
+}
+
+int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, const float *m1a, const float *m1b,
+                           float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
+                           double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
+                           float *v_part, double *part, void *stream) {
+    if (!m1a || !m1b) return fail(DFX_EINVAL, "dfx_adam_step_factored: NULL buffer");
+    return adam_impl(g, pl, x, nullptr, m1a, m1b, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, scal, u_part,
+                     v_part, part, stream);
+}
+
+int dfx_lerp(float *m, const float *g, int64_t n, double weight, void *stream) {
+    if (!m || !g || n <= 0) return fail(DFX_EINVAL, "dfx_lerp: bad argument");
+    hipLaunchKernelGGL(k_lerp, dim3(ew_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, m, g, (long long)n,
+                       (float)weight);
+    DFX_LAUNCH_CHECK("dfx_lerp");
+    return 0;
 }
 
 int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,

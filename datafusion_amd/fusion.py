@@ -423,9 +423,17 @@ class FusionAdam(Fusion):
     loss() as a custom torch.autograd.Function over the same HIP kernels, loss.backward(),
     torch.optim.Adam.step()."""
 
-    def __init__(self, *args, fused: bool = True, betas=(0.9, 0.999), adam_eps: float = 1e-8, **kwargs):
+    def __init__(self, *args, fused: bool = True, betas=(0.9, 0.999), adam_eps: float = 1e-8,
+                 moment1: str = "factored", **kwargs):
+        """moment1="factored" (default, fused=True only): exp_avg is linear in the gradients, which are all of the
+        form mask * (A[z,x,y] + B[t,l,x/r,y/r]), so it is kept as two small arrays advanced by dfx_lerp and never
+        stored as a 5-D vector: x and exp_avg_sq are the only volumes read and written (4N words per iteration).
+        moment1="explicit": exp_avg is a 5-D vector as in torch.optim.Adam (6N words)."""
+        if moment1 not in ("factored", "explicit"):
+            raise ValueError("moment1 must be 'factored' or 'explicit'")
         super().__init__(*args, **kwargs)
         self.fused = fused
+        self.moment1 = moment1
         self.betas, self.adam_eps = betas, adam_eps
         self._m1 = self._m2 = None
         self._adam_step = 0
@@ -449,7 +457,10 @@ class FusionAdam(Fusion):
         w1, w2 = float(self.weights["spatial"]), float(self.weights["spectro_temporal"])
         x = self.x.data
         # a fresh optimizer per call, like fusion.py:325
-        self._m1 = torch.zeros_like(x)
+        fact = self.moment1 == "factored"
+        self._m1 = None if fact else torch.zeros_like(x)
+        self._m1a = torch.zeros_like(k.u) if fact else None
+        self._m1b = torch.zeros_like(k.v) if fact else None
         self._m2 = torch.zeros_like(x)
         self._adam_step = 0
         self._project(x)                                   # u(x), v(x) for the first loss / gradient
@@ -460,9 +471,13 @@ class FusionAdam(Fusion):
             A = k.diff_scale(self._cmos_loc, k.u, self._cmask_loc if self.mask_noise else None, -2.0 * w1)
             B = k.diff_scale(self.spc, k.v, self._smask_f if self.mask_noise else None, -2.0 * w2)
             self._adam_step += 1
+            if fact:                                    # exp_avg.lerp_(grad, 1 - beta1) on its two factors
+                k.lerp(self._m1a, A, 1.0 - self.betas[0])
+                k.lerp(self._m1b, B, 1.0 - self.betas[0])
             k.adam_step(x, self._m1, self._m2, A, B,
                         self._cmask_loc if self.mask_noise else None,                  # fusion.py:274-278
-                        lr, self.betas[0], self.betas[1], self.adam_eps, self._adam_step, non_neg)
+                        lr, self.betas[0], self.betas[1], self.adam_eps, self._adam_step, non_neg,
+                        m1a=self._m1a, m1b=self._m1b)
             c.sum_(k.v)
             tolerance = None
             if self.tol is not None:                                            # fusion.py:348

@@ -155,23 +155,37 @@ class HipKernels:
                                          cabi.ptr(self.part), s), "dfx_reduce_u")
 
     @_on_device
-    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step: int, non_neg: bool) -> None:
-        """One fused Adam iteration: x, m1, m2 in place; u(x_new) -> self.u, local v partial -> self.v;
-        ADAM_DD = ||dx||^2, ADAM_XX = ||x_new||^2."""
-        self._chk(x, m1, m2, A, B, mask)
-        assert x.numel() == m1.numel() == m2.numel() == self.N
+    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step: int, non_neg: bool, m1a=None,
+                  m1b=None) -> None:
+        """One fused Adam iteration: x, m2 (and m1) in place; u(x_new) -> self.u, local v partial -> self.v;
+        ADAM_DD = ||dx||^2, ADAM_XX = ||x_new||^2.  m1=None: the first moment is mask * (m1a + m1b), already advanced
+        by lerp() for this step (dfx_adam_step_factored)."""
+        self._chk(x, m1, m2, A, B, mask, m1a, m1b)
+        assert x.numel() == m2.numel() == self.N and (m1 is None or m1.numel() == self.N)
         assert A.numel() == self.S and B.numel() == self.M * self.Xs * self.Ys and (mask is None or mask.numel() == self.S)
         g, pl = self._g()
         s = self._stream()
-        cabi.check(self._timed("adam", self.lib.dfx_adam_step, g, pl, cabi.ptr(x), cabi.ptr(m1), cabi.ptr(m2),
-                               cabi.ptr(A), cabi.ptr(B), cabi.ptr(mask), lr, beta1, beta2, eps, step, int(non_neg),
-                               cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part),
-                               cabi.ptr(self.part), s), "dfx_adam_step")
+        tail = (cabi.ptr(m2), cabi.ptr(A), cabi.ptr(B), cabi.ptr(mask), lr, beta1, beta2, eps, step, int(non_neg),
+                cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part), cabi.ptr(self.part), s)
+        if m1 is not None:
+            cabi.check(self._timed("adam", self.lib.dfx_adam_step, g, pl, cabi.ptr(x), cabi.ptr(m1), *tail),
+                       "dfx_adam_step")
+        else:
+            assert m1a.numel() == self.S and m1b.numel() == self.M * self.Xs * self.Ys
+            cabi.check(self._timed("adamf", self.lib.dfx_adam_step_factored, g, pl, cabi.ptr(x), cabi.ptr(m1a),
+                                   cabi.ptr(m1b), *tail), "dfx_adam_step_factored")
         cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
                                          cabi.ptr(self.part), s), "dfx_reduce_u")
         if self._v_own is not None:
             cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), 0, self.M, s),
                        "dfx_reduce_v")
+
+    @_on_device
+    def lerp(self, m, g, weight: float) -> None:
+        """m += weight * (g - m) on small arrays (torch's exp_avg.lerp_)."""
+        self._chk(m, g)
+        assert m.numel() == g.numel()
+        cabi.check(self.lib.dfx_lerp(cabi.ptr(m), cabi.ptr(g), m.numel(), weight, self._stream()), "dfx_lerp")
 
     @_on_device
     def sqnorm_v(self) -> None:

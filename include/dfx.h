@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 110
+#define DFX_VERSION 111
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -150,6 +150,18 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
 int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, float *m2, const float *A,
                   const float *B, const float *mask, double lr, double beta1, double beta2, double eps, int32_t step,
                   int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream);
+
+/* The same step with the FIRST moment kept in factored form.  exp_avg is linear in the gradients and every gradient
+ * is mask * (A[z,x,y] + B[t,l,x/r,y/r]), so m1 = mask * (m1a[z,x,y] + m1b[t,l,x/r,y/r]) exactly and the 5-D m1 array
+ * never exists: the caller advances the factors with dfx_lerp(m1a, A, 1-beta1), dfx_lerp(m1b, B, 1-beta1) (torch's
+ * exp_avg.lerp_) BEFORE this call; x and m2 are read and written (4N words instead of 6N).  No counterpart for m2:
+ * g^2 has cross terms A*B that do not factor. */
+int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, const float *m1a, const float *m1b,
+                           float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
+                           double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
+                           float *v_part, double *part, void *stream);
+/* m[i] += (float)weight * (g[i] - m[i]), i < n  (torch.lerp_ as torch.optim.Adam applies it to exp_avg). */
+int dfx_lerp(float *m, const float *g, int64_t n, double weight, void *stream);
 
 /* u[i] = sum over the n_chunks/cpb rows of u_part[row][i] (i < nZ*X*Y); scal[DFX_S_UU] = sum u^2. */
 int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,

@@ -90,13 +90,26 @@ class CpuStandIn:
             s[cabi.S_XX] = (x.double() ** 2).sum()
             s[cabi.S_XP] = (x.double() * p.double()).sum()
 
-    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg):
+    def lerp(self, m, g, weight):
+        m.lerp_(g.reshape(m.shape), weight)
+
+    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, m1a=None, m1b=None):
         n_z, X, Y = self.shape[2:]
-        g = A.reshape(1, 1, n_z, X, Y) + B.repeat_interleave(self.r, 2).repeat_interleave(self.r, 3).unsqueeze(2)
+
+        def expand(a, b):
+            return a.reshape(1, 1, n_z, X, Y) + b.reshape(self.v.shape).repeat_interleave(self.r, 2) \
+                .repeat_interleave(self.r, 3).unsqueeze(2)
+
+        g = expand(A, B)
         if mask is not None:
             g = g * mask.reshape(1, 1, n_z, X, Y)
         x_old = x.clone()
-        m1.lerp_(g, 1 - beta1)
+        if m1 is not None:
+            m1.lerp_(g, 1 - beta1)
+        else:                                   # factored first moment, already advanced by lerp()
+            m1 = expand(m1a, m1b)
+            if mask is not None:
+                m1 = m1 * mask.reshape(1, 1, n_z, X, Y)
         m2.mul_(beta2).addcmul_(g, g, value=1 - beta2)
         bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
         x.addcdiv_(m1, (m2.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)

@@ -28,7 +28,7 @@ def _worker(rank, world, port, case, q):
         f = FusionCG(spc, cmos, residual=case.get("residual", "factored"), **kw)
         x, _, _ = f(case["iters"], return_numpy=False)
     else:
-        f = FusionAdam(spc, cmos, fused=case.get("fused", True), **kw)
+        f = FusionAdam(spc, cmos, fused=case.get("fused", True), moment1=case.get("moment1", "factored"), **kw)
         x, _, _ = f(lr=1e-7, max_iterations=case["iters"], return_numpy=False)
     l1, l2 = f.loss()
     parts = [None] * world
@@ -86,6 +86,10 @@ def test_gloo_cg_explicit_residual():
 
 def test_gloo_adam_fused():
     _check(dict(method="adam", init="baseline", tol=None, mask=True, defer=True, iters=4), 29613)
+
+
+def test_gloo_adam_fused_explicit_first_moment():
+    _check(dict(method="adam", init="baseline", tol=None, mask=False, defer=True, iters=4, moment1="explicit"), 29616)
 
 
 def test_gloo_adam_autograd():

@@ -114,7 +114,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libdfx.so does not export {n}"
-    assert cabi.lib().dfx_version() == 110
+    assert cabi.lib().dfx_version() == 111
 
 
 def test_header_constants_match_python_mirror():
@@ -260,6 +260,11 @@ def test_host_logic_adam(golden, cpu_backend, fused):
     from datafusion_amd import FusionAdam
     for name, mask, nn in (("adam_t6l4z3_32", False, False), ("adam_t6l4z3_32_mask_nn", True, True)):
         g = golden(name)
+        if fused:
+            fe = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu",
+                            mask_noise=mask, moment1="explicit")
+            xe, _, _ = fe(lr=float(g["lr"]), max_iterations=5, non_neg=nn)
+            assert O.rel_l2(xe, g["x_5"]) <= 2e-5
         f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device="cpu", mask_noise=mask,
                        fused=fused)
         l1, l2 = f.loss()

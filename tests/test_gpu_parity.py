@@ -103,6 +103,11 @@ def test_adam_matches_reference(golden, name, mask, nn, fused):
     f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, mask_noise=mask,
                    fused=fused)
     assert O.rel_l2(f.x.cpu(), g["x0"]) <= TIGHT
+    if fused:   # exp_avg as a 5-D vector (torch.optim.Adam's layout) gives the same iterate as the factored default
+        fe = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, mask_noise=mask,
+                        moment1="explicit")
+        xe, _, _ = fe(lr=float(g["lr"]), max_iterations=5, non_neg=nn)
+        assert O.rel_l2(xe, g["x_5"]) <= TIGHT
     l1, l2 = f.loss()
     assert np.allclose([float(l1), float(l2)], g["loss0"], rtol=1e-3)
     # first gradient (before the mask of fusion.py:274-278, which the product fuses into the kernel)
@@ -331,6 +336,19 @@ def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     assert O.rel_l2(m24.cpu(), e2.cpu()) <= 1e-6
     u4, v4 = proj(x4.double())
     assert O.rel_l2(k.u.cpu(), u4.cpu()) <= 1e-6 and O.rel_l2(k.v.cpu(), v4.cpu()) <= 1e-6
+    # the same step with the first moment in factored form: m1 = mask * (m1a + m1b), advanced by dfx_lerp
+    m1a0, m1b0 = torch.randn_like(A) * 0.1, torch.randn_like(B) * 0.1
+    m1_full = (m1a0[None, None] + m1b0.repeat_interleave(r, 2).repeat_interleave(r, 3)[:, :, None]) * mask[None, None]
+    x5, m15, m25 = x.clone(), m1_full.contiguous().clone(), m2.clone()
+    k.adam_step(x5, m15, m25, A, B, mask, 1e-2, 0.9, 0.999, 1e-8, 3, True)            # explicit reference run
+    x6, m26, m1a, m1b = x.clone(), m2.clone(), m1a0.clone(), m1b0.clone()
+    k.lerp(m1a, A, 1.0 - 0.9)
+    k.lerp(m1b, B, 1.0 - 0.9)
+    assert torch.equal(m1a, m1a0.lerp(A, 0.1)) or O.rel_l2(m1a.cpu(), m1a0.lerp(A, 0.1).cpu()) <= 1e-7
+    k.adam_step(x6, None, m26, A, B, mask, 1e-2, 0.9, 0.999, 1e-8, 3, True, m1a=m1a, m1b=m1b)
+    assert O.rel_l2(x6.cpu(), x5.cpu()) <= 1e-6 and O.rel_l2(m26.cpu(), m25.cpu()) <= 1e-7
+    u6, v6 = proj(x6.double())
+    assert O.rel_l2(k.u.cpu(), u6.cpu()) <= 1e-6 and O.rel_l2(k.v.cpu(), v6.cpu()) <= 1e-6
     # small-space difference kernel
     a2, b2 = torch.randn(n_z, X, Y, device=DEV), torch.randn(n_z, X, Y, device=DEV)
     assert torch.equal(k.diff_scale(a2, b2, mask, -0.6), (torch.tensor(-0.6) * (a2 - b2)) * mask)
