@@ -43,7 +43,8 @@ def _worker(rank, world, port, case, q):
 def _run(case, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    world = case.get("world", 2)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=120)
@@ -82,6 +83,11 @@ def test_gloo_cg_textbook_tolerance_break_random_init():
 
 def test_gloo_cg_explicit_residual():
     _check(dict(method="cg", init="baseline", tol=None, mask=False, defer=True, iters=8, residual="explicit"), 29615)
+
+
+def test_gloo_cg_four_ranks_uneven_planes():
+    """5 planes over 4 ranks: 2 + 1 + 1 + 1."""
+    _check(dict(method="cg", init="baseline", tol=3e-3, mask=False, defer=True, iters=12, world=4), 29617)
 
 
 def test_gloo_adam_fused():
