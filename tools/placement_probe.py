@@ -35,12 +35,30 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--keep", type=int, default=3, help="keep at most this many earlier pairs allocated")
+    ap.add_argument("--arena-gib", type=int, default=0,
+                    help="instead: ONE allocation of this size; x and p are windows sliding through it (--stride-gib)")
+    ap.add_argument("--stride-gib", type=float, default=4.0)
     a = ap.parse_args()
     shape = tuple(int(v) for v in a.shape.split(","))
     k = HipKernels(*shape, 4, "cuda:0")
     k.new_factored_residual()
     k.ra.zero_(), k.rb.zero_()
     nbytes = 4 * k.N
+    if a.arena_gib:
+        arena = torch.zeros(a.arena_gib << 28, device="cuda:0")          # floats
+        stride = int(a.stride_gib * (1 << 28))
+        off = 0
+        while off + 2 * k.N <= arena.numel():
+            x = arena[off:off + k.N].view(k.shape)
+            for gap in (0, 1 << 20):                                      # p right behind x, and 4 MiB further
+                if off + 2 * k.N + gap > arena.numel():
+                    continue
+                p = arena[off + k.N + gap:off + 2 * k.N + gap].view(k.shape)
+                ms = time_sweep(k, x, p, a.reps)
+                print(f"arena offset {off / (1 << 28):6.1f} GiB gap {gap * 4 >> 20} MiB: sweep {ms:.3f} ms = "
+                      f"{4 * nbytes / ms / 1e6:.0f} GB/s", flush=True)
+            off += stride
+        return
     kept = []
     for i in range(a.rounds):
         x = torch.zeros(k.shape, device="cuda:0")
