@@ -273,6 +273,22 @@ def test_host_logic_adam(golden, cpu_backend, fused):
         assert O.rel_l2(x, g["x_5"]) <= 2e-5
 
 
+def test_host_logic_adam_tolerance_break(golden, cpu_backend):
+    from datafusion_amd import FusionAdam
+    g = golden("adam_tol_t6l4z3_32")
+    for kw in ({}, {"moment1": "explicit"}, {"fused": False}):
+        f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=float(g["tol"]), device="cpu", **kw)
+        x, _, _ = f(lr=float(g["lr"]), max_iterations=12, non_neg=True)
+        assert f.curr_iter == int(g["curr_iter"]) and O.rel_l2(x, g["x"]) <= 2e-5
+
+
+def test_oracle_reproduces_adam_tolerance_golden(golden):
+    g = golden("adam_tol_t6l4z3_32")
+    pb = O.prepare(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=float(g["tol"]))
+    x = O.adam(pb, float(g["lr"]), 12, non_neg=True)
+    assert pb.curr_iter == int(g["curr_iter"]) and O.rel_l2(x, g["x"]) <= 1e-6
+
+
 def test_operator_mirrors_refuse_cpu_tensors():
     from datafusion_amd import SumOperator, SumPoolOperator, _cabi as cabi
     with pytest.raises(cabi.DfxError, match="no CPU path"):

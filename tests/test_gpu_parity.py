@@ -422,3 +422,26 @@ def test_factored_residual_stays_well_conditioned():
         s = f.k.scal.cpu()
         ratio = float((f.k.M * s[cabi.S_RA2] + 6 * 16 * s[cabi.S_RB2]) / s[cabi.S_RR])
         assert 0.5 <= ratio <= 8.0, ratio
+
+
+@pytest.mark.parametrize("kw", [{}, {"moment1": "explicit"}, {"fused": False}])
+def test_adam_tolerance_break_matches_reference(golden, kw):
+    """FusionAdam leaves its loop through the tolerance test (fusion.py:348-358) at the reference's iteration."""
+    from datafusion_amd import FusionAdam
+    g = golden("adam_tol_t6l4z3_32")
+    f = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=float(g["tol"]), device=DEV, **kw)
+    x, _, _ = f(lr=float(g["lr"]), max_iterations=12, non_neg=True)
+    assert f.curr_iter == int(g["curr_iter"])
+    assert O.rel_l2(x, g["x"]) <= TIGHT
+
+
+def test_cg_verbose_history_with_masks_matches_reference(golden):
+    """The masked loss variants (fusion.py:216-223) through the verbose history of a mask_noise=True run."""
+    from datafusion_amd import FusionCG
+    g = golden("cg_cells_t8l4z5_32_mask")
+    f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, verbose=True,
+                 mask_noise=True)
+    f(10)
+    h, hr = f.history, g["hist"]
+    assert np.allclose(h[:5, :3], hr[:5, :3], rtol=2e-3, atol=1e-12)
+    assert np.allclose(h[:3, 3], hr[:3, 3], rtol=2e-3)
