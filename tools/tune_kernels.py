@@ -53,10 +53,14 @@ def run(a, pad, n_t, n_l, n_z, X, Y, dev, arena=None):
     for k in ks:
         k.scal[cabi.S_ALPHA] = 1e-3
         k.scal[cabi.S_BETA] = 0.5
-    res = {i: {"sweep": [], "bcast": [], "proj": [], "adam": []} for i in range(len(ks))}
+    for k in ks:
+        k.new_factored_residual()
+        k.ra.zero_(), k.rb.zero_()
+    m1a, m1b = torch.zeros_like(ks[0].u), torch.zeros_like(ks[0].v)
+    res = {i: {"sweep": [], "bcast": [], "proj": [], "adam": [], "sweepf": [], "adamf": []} for i in range(len(ks))}
     for rnd in range(a.rounds + 1):
         for i, k in enumerate(ks):
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
             e[0].record()
             k.sweep(cabi.SWEEP_XP, vec[0], vec[1], vec[2])
             e[1].record()
@@ -66,8 +70,14 @@ def run(a, pad, n_t, n_l, n_z, X, Y, dev, arena=None):
             e[3].record()
             k.adam_step(vec[0], vec[1], vec[2], k.u, k.v, None, 1e-8, 0.9, 0.999, 1e-8, 3, False)
             e[4].record()
+            k.sweep(cabi.SWEEP_XP, vec[0], None, vec[2], factored=True)
+            e[5].record()
+            k.adam_step(vec[0], None, vec[2], k.u, k.v, None, 1e-8, 0.9, 0.999, 1e-8, 3, False, m1a=m1a, m1b=m1b)
+            e[6].record()
             torch.cuda.synchronize()
             if rnd:
+                res[i]["sweepf"].append(e[4].elapsed_time(e[5]))
+                res[i]["adamf"].append(e[5].elapsed_time(e[6]))
                 res[i]["proj"].append(e[2].elapsed_time(e[3]))
                 res[i]["adam"].append(e[3].elapsed_time(e[4]))
                 res[i]["sweep"].append(e[0].elapsed_time(e[1]))
@@ -81,7 +91,8 @@ def run(a, pad, n_t, n_l, n_z, X, Y, dev, arena=None):
             print("   sweep rounds:", " ".join(f"{t:.2f}" for t in res[i]["sweep"]), flush=True)
         print(f"{lib} zc={k.plan.zc} steps={k.plan.steps} cpb={k.plan.cpb} blocks={k.plan.n_blocks}: sweep(+reduce_u) med {ms:.3f} ms "
               f"min {sw[0]:.3f} -> {20 * n / ms / 1e6:.0f} GB/s | bcast med {mb:.3f} min {bc[0]:.3f} -> "
-              f"{8 * n / mb / 1e6:.0f} GB/s | iter {ms + mb:.3f} ms | project med {sorted(res[i]['proj'])[len(bc) // 2]:.3f} | adam med {sorted(res[i]['adam'])[len(bc) // 2]:.3f}", flush=True)
+              f"{8 * n / mb / 1e6:.0f} GB/s | iter {ms + mb:.3f} ms | project med {sorted(res[i]['proj'])[len(bc) // 2]:.3f} | adam med {sorted(res[i]['adam'])[len(bc) // 2]:.3f} | factored: sweep med "
+              f"{sorted(res[i]['sweepf'])[len(bc) // 2]:.3f} adam med {sorted(res[i]['adamf'])[len(bc) // 2]:.3f}", flush=True)
 
 
 if __name__ == "__main__":
