@@ -139,7 +139,8 @@ def main():
                          "third 5-D vector, 7N words/iter")
     ap.add_argument("--moment1", default="factored", choices=["factored", "explicit"],
                     help="--method adam: first moment as two small-space factors (4N words/iter) or a 5-D vector (6N)")
-    ap.add_argument("--comm-slices", type=int, default=4, help="launches a z-sharded sweep is cut into (overlap of the v all-reduce)")
+    ap.add_argument("--comm-slices", default="auto",
+                    help="launches a z-sharded sweep is cut into (overlap of the v all-reduce): auto or a number")
     ap.add_argument("--single", action="store_true", help="time only --residual, not the other representation as well")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--target-blocks", type=int, default=0)
@@ -177,7 +178,7 @@ def main():
         """Construct, warm up, time exactly a.steps iterations of one residual mode; max over ranks."""
         f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
                      mask_noise=False, total_energy=1, device=dev, seed=42, group=group, defer_x=not a.no_defer,
-                     target_blocks=a.target_blocks, residual=residual, comm_slices=a.comm_slices)
+                     target_blocks=a.target_blocks, residual=residual, comm_slices=a.comm_slices if a.comm_slices == "auto" else int(a.comm_slices))
         f.start()
         f.iterate(a.warmup)
         f.k.timing = {}

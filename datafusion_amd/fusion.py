@@ -236,7 +236,7 @@ class Fusion:
 class FusionCG(Fusion):
     """Conjugate gradient on the normal equations (fusion.py:389-496)."""
 
-    def __init__(self, *args, comm_slices: int = 4, residual: str = "factored", **kwargs):
+    def __init__(self, *args, comm_slices: int | str = "auto", residual: str = "factored", **kwargs):
         """residual="factored" (default): r = b - A x is kept as the two small arrays it is made of,
         r = ra[z,x,y] + rb[t,l,x/r,y/r] (include/dfx.h, dfx_resid_update) - one 4N-word pass per iteration and
         two resident 5-D vectors (x, p).  residual="explicit": r is a third 5-D vector updated by dfx_bcast
@@ -248,9 +248,22 @@ class FusionCG(Fusion):
         self.w1 = self.weights["spatial"]
         self.w2 = self.weights["spectro_temporal"]
         self._r = self._p = None
-        self.comm_slices = int(comm_slices)
+        self.comm_slices = self._auto_slices() if comm_slices == "auto" else int(comm_slices)
         self._pending_x = False
         self._stopped = False
+
+    def _auto_slices(self) -> int:
+        """How many launches to cut a sharded sweep into.  Every band's all-reduce but the last hides behind the
+        bands still being swept; bands shrink linearly (HipKernels._slice_bounds), so with k launches the exposed
+        one carries 2/(k(k+1)) of v.  Each extra launch costs ~50 us on an MI355X (measured with a one-rank RCCL
+        group at C2: 2.81 / 2.86 / 2.96 / 3.15 ms per iteration for k = 1 / 2 / 4 / 8); the all-reduce is priced at
+        an assumed 70 GB/s + 30 us over xGMI.  C2-sized shards (16 MiB of v) get k = 2, the 256 MiB of configs 3 / 4
+        k = 6."""
+        if self.comm.size <= 1 and not self.comm._always:
+            return 1
+        t_ar = 4.0 * self.n_times * self.n_lambdas * self.spc.shape[-2] * self.spc.shape[-1] / 70e9 + 30e-6
+        cost = {k: t_ar * 2.0 / (k * (k + 1)) + 50e-6 * (k - 1) for k in range(1, cabi.MAX_SLICES + 1)}
+        return min(cost, key=cost.get)
 
     def _sweep(self, mode) -> None:
         """One pass over x, r, p.  When the volume is z-sharded the pass is cut into `comm_slices` launches along
