@@ -19,7 +19,7 @@ class Geom(C.Structure):
 
 class Plan(C.Structure):
     _fields_ = [("fast", C.c_int32), ("zc", C.c_int32), ("n_zchunks", C.c_int32), ("steps", C.c_int32),
-                ("n_chunks", C.c_int32), ("cpb", C.c_int32), ("n_blocks", C.c_int32), ("pad_", C.c_int32),
+                ("n_chunks", C.c_int32), ("cpb", C.c_int32), ("n_blocks", C.c_int32), ("zs", C.c_int32),
                 ("u_part_elems", C.c_int64),
                 ("v_part_elems", C.c_int64), ("part_elems", C.c_int64)]
 

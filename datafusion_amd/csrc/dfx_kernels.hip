@@ -69,6 +69,7 @@ struct Geo {
     int nZ, X, Y, Xs, Ys, r;
     int WT;        // wave tiles per plane (fast path): ceil(nblk / BW), BW = 64, 16, 4 blocks per wave for r = 2, 4, 8
     int nblk;      // r x r blocks per plane = Xs*Ys
+    int zs;        // planes per z-chunk of the plan in use (<= the kernel's ZC); set by the entry points
 };
 
 int make_geo(const dfx_geom *g, Geo *o) {
@@ -230,8 +231,10 @@ struct SweepArgs {
     int row0;      // first row of `part` this launch writes
 };
 
-template <int MODE, int ZC, int R, bool FACT, bool FULL>
-__device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0, int m1, int ms, long long off,
+// ZN = planes of this z-chunk that exist (ZC for every chunk but possibly the last): a compile-time count, so a
+// ragged chunk runs the same straight-line code as a full one over fewer planes
+template <int MODE, int ZC, int R, bool FACT, int ZN>
+__device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, int ms, long long off,
                                             const LaneMap<R> &L, float fa, float fb, const f4 (&rav)[ZC],
                                             f4 (&uacc)[ZC], double &dpp, double &dxx, double &dxp) {
     float *vbase = a.v_part + (long long)blockIdx.y * a.q.M * a.q.Ps;
@@ -248,11 +251,8 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
             f4 xv[ZB], rv[ZB], pv[ZB];
 #pragma unroll
             for (int j = 0; j < ZB; ++j) {
-                {
-                    // a ragged last z-chunk re-reads its last plane instead of branching around the loads (the
-                    // branches made the compiler wait for every load separately); stores and sums stay predicated
-                    const int kk = FULL ? g + j : min(g + j, zcnt - 1);
-                    const long long i = base + (long long)kk * a.q.P;
+                if (g + j < ZN) {
+                    const long long i = base + (long long)(g + j) * a.q.P;
                     if (MODE == DFX_SWEEP_PROJECT) {
                         xv[j] = ld4s(a.x + i);
                     } else if (MODE == DFX_SWEEP_XP) {
@@ -270,7 +270,7 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int zcnt, int m0
             }
 #pragma unroll
             for (int j = 0; j < ZB; ++j) {
-                if (FULL || g + j < zcnt) {
+                if (g + j < ZN) {
                     const long long i = base + (long long)(g + j) * a.q.P;
                     f4 pn;
                     if (MODE == DFX_SWEEP_PROJECT) {
@@ -311,8 +311,8 @@ template <int MODE, int ZC, int R, bool FACT>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(const SweepArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
-    const int z0 = blockIdx.y * ZC;
-    const int zcnt = min(ZC, a.q.nZ - z0);
+    const int z0 = blockIdx.y * a.q.zs;   // z-chunks are balanced: zs = ceil(nZ / n_zchunks) <= ZC planes each
+    const int zcnt = min(min(a.q.zs, ZC), a.q.nZ - z0);
     const int gz = gridDim.z, bz = blockIdx.z;
     double dpp = 0, dxx = 0, dxp = 0;
     // a wave owns LaneMap<R>::BW consecutive r x r blocks of the plane; only the last wave can have idle lanes
@@ -337,10 +337,17 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_sweep_fast(con
             f4 uacc[ZC];
 #pragma unroll
             for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (zcnt == ZC)
-                sweep_steps<MODE, ZC, R, FACT, true>(a, zcnt, m0, m1, ms, off, L, fa, fb, rav, uacc, dpp, dxx, dxp);
-            else
-                sweep_steps<MODE, ZC, R, FACT, false>(a, zcnt, m0, m1, ms, off, L, fa, fb, rav, uacc, dpp, dxx, dxp);
+#define DFX_ZN_CASE(n)                                                                                     \
+    case n:                                                                                                \
+        if constexpr (n <= ZC)                                                                             \
+            sweep_steps<MODE, ZC, R, FACT, n>(a, m0, m1, ms, off, L, fa, fb, rav, uacc, dpp, dxx, dxp);   \
+        break;
+            switch (zcnt) {
+                DFX_ZN_CASE(1) DFX_ZN_CASE(2) DFX_ZN_CASE(3) DFX_ZN_CASE(4)
+                DFX_ZN_CASE(5) DFX_ZN_CASE(6) DFX_ZN_CASE(7) DFX_ZN_CASE(8)
+                default: break;
+            }
+#undef DFX_ZN_CASE
             // one u_part row per workgroup of the slab axis: chunk 0 writes it, later chunks add to it (same lane,
             // same order in every run: deterministic; a sliced sweep continues the rows of the slices before it)
             float *up = a.u_part + (long long)bz * a.q.S + off;
@@ -374,13 +381,13 @@ struct BcastArgs {
     int steps, n_chunks, cpb;
 };
 
-template <int ZC, int R, bool HAS_IN, bool HAS_MASK, bool FULL>
-__device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0, int m1, int ms, long long off,
+template <int ZC, int R, bool HAS_IN, bool HAS_MASK, int ZN>
+__device__ __forceinline__ void bcast_steps(const BcastArgs &a, int m0, int m1, int ms, long long off,
                                             const LaneMap<R> &L, float cb, const f4 (&av)[ZC], const f4 (&mk)[ZC],
                                             double &drr) {
     // MU slabs per trip: one wave per SIMD is the fastest residency for these kernels, so the loads in
     // flight per lane (MU * ZC float4) are what hides HBM latency
-    constexpr int MU = (DFX_BCAST_INFLIGHT / ZC) > 0 ? DFX_BCAST_INFLIGHT / ZC : 1;
+    constexpr int MU = (DFX_BCAST_INFLIGHT / ZN) > 0 ? DFX_BCAST_INFLIGHT / ZN : 1;
     for (int m = m0; m < m1; m += ms * MU) {
         f4 b[MU];
         f4 iv[MU][ZC];
@@ -392,8 +399,7 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0
                 if (HAS_IN) {
                     const long long base = (long long)mm * a.q.S + off;
 #pragma unroll
-                    for (int k = 0; k < ZC; ++k)   // ragged chunk: re-read the last plane rather than branch (see sweep_steps)
-                        iv[u][k] = ld4s(a.in + base + (long long)(FULL ? k : min(k, zcnt - 1)) * a.q.P);
+                    for (int k = 0; k < ZN; ++k) iv[u][k] = ld4s(a.in + base + (long long)k * a.q.P);
                 }
             }
         }
@@ -404,8 +410,8 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int zcnt, int m0
                 const long long base = (long long)mm * a.q.S + off;
                 float rr = 0.f;
 #pragma unroll
-                for (int k = 0; k < ZC; ++k) {
-                    if (FULL || k < zcnt) {
+                for (int k = 0; k < ZN; ++k) {
+                    {
                         f4 o = av[k] + (HAS_MASK ? mk[k] * b[u] : b[u]);
                         if (HAS_IN) o += iv[u][k];
                         st4s(a.out + base + (long long)k * a.q.P, o);
@@ -422,8 +428,8 @@ template <int ZC, int R, bool HAS_IN, bool HAS_MASK>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(const BcastArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
-    const int z0 = blockIdx.y * ZC;
-    const int zcnt = min(ZC, a.q.nZ - z0);
+    const int z0 = blockIdx.y * a.q.zs;   // z-chunks are balanced: zs = ceil(nZ / n_zchunks) <= ZC planes each
+    const int zcnt = min(min(a.q.zs, ZC), a.q.nZ - z0);
     const int m0 = blockIdx.z, ms = gridDim.z, m1 = a.q.M;
     double drr = 0;
     const LaneMap<R> L(a.q, wt, lane);
@@ -444,10 +450,17 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_bcast_fast(con
                 }
             }
         }
-        if (zcnt == ZC)
-            bcast_steps<ZC, R, HAS_IN, HAS_MASK, true>(a, zcnt, m0, m1, ms, off, L, cb, av, mk, drr);
-        else
-            bcast_steps<ZC, R, HAS_IN, HAS_MASK, false>(a, zcnt, m0, m1, ms, off, L, cb, av, mk, drr);
+#define DFX_ZN_CASE(n)                                                                               \
+    case n:                                                                                          \
+        if constexpr (n <= ZC)                                                                       \
+            bcast_steps<ZC, R, HAS_IN, HAS_MASK, n>(a, m0, m1, ms, off, L, cb, av, mk, drr);        \
+        break;
+        switch (zcnt) {
+            DFX_ZN_CASE(1) DFX_ZN_CASE(2) DFX_ZN_CASE(3) DFX_ZN_CASE(4)
+            DFX_ZN_CASE(5) DFX_ZN_CASE(6) DFX_ZN_CASE(7) DFX_ZN_CASE(8)
+            default: break;
+        }
+#undef DFX_ZN_CASE
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     block_store3(drr, 0.0, 0.0, a.part + bid * DFX_NPART);
@@ -511,33 +524,33 @@ struct AdamSlab {
     f4 b, mb;
 };
 
-template <int ZC, int R, bool M1F>
+template <int ZC, int R, bool M1F, int ZN>
 __device__ __forceinline__ void adam_load(const AdamArgs &a, AdamSlab<ZC> &s, const LaneMap<R> &L, int m,
-                                          long long off, int zcnt) {
+                                          long long off) {
     const long long base = (long long)m * a.q.S + off;
     s.b = L.bload(a.B + (long long)m * a.q.Ps);
     s.mb = (f4){0.f, 0.f, 0.f, 0.f};
     if (M1F) s.mb = L.bload(a.m1b + (long long)m * a.q.Ps);
 #pragma unroll
-    for (int k = 0; k < ZC; ++k) {   // ragged chunk: re-read the last plane rather than branch (see sweep_steps)
-        const long long i = base + (long long)min(k, zcnt - 1) * a.q.P;
+    for (int k = 0; k < ZN; ++k) {
+        const long long i = base + (long long)k * a.q.P;
         s.x[k] = ld4s(a.x + i);
         if (!M1F) s.e1[k] = ld4s(a.m1 + i);
         s.e2[k] = ld4s(a.m2 + i);
     }
 }
 
-template <int ZC, int R, bool HAS_MASK, bool M1F>
+template <int ZC, int R, bool HAS_MASK, bool M1F, int ZN>
 __device__ __forceinline__ void adam_apply(const AdamArgs &a, AdamSlab<ZC> &s, const LaneMap<R> &L, int m,
-                                           long long off, int zcnt, const f4 (&av)[ZC], const f4 (&mk)[ZC],
+                                           long long off, const f4 (&av)[ZC], const f4 (&mk)[ZC],
                                            const f4 (&m1av)[ZC], f4 (&uacc)[ZC], float *vbase, int lane, double &ddd,
                                            double &dxx) {
     const long long base = (long long)m * a.q.S + off;
     f4 s4 = {0.f, 0.f, 0.f, 0.f};
     float dd = 0.f, xx = 0.f;
 #pragma unroll
-    for (int k = 0; k < ZC; ++k) {
-        if (k < zcnt) {
+    for (int k = 0; k < ZN; ++k) {
+        {
             const long long i = base + (long long)k * a.q.P;
             f4 g = av[k] + s.b;
             if (HAS_MASK) g *= mk[k];
@@ -561,12 +574,33 @@ __device__ __forceinline__ void adam_apply(const AdamArgs &a, AdamSlab<ZC> &s, c
     dxx += (double)xx;
 }
 
+// the slabs m0, m0 + gz, ... < m1e of one u_part chunk, ZN live planes, two register sets in ping-pong
+template <int ZC, int R, bool HAS_MASK, bool M1F, int ZN>
+__device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &L, int m0, int m1e, int gz,
+                                           long long off, const f4 (&av)[ZC], const f4 (&mk)[ZC],
+                                           const f4 (&m1av)[ZC], f4 (&uacc)[ZC], float *vbase, int lane, double &ddd,
+                                           double &dxx) {
+    AdamSlab<ZC> sa, sb;   // one being updated, the other in flight
+    int m = m0;
+    if (m < m1e) adam_load<ZC, R, M1F, ZN>(a, sa, L, m, off);
+    while (m < m1e) {
+        const int mb = m + gz, ma = mb + gz;
+        if (mb < m1e) adam_load<ZC, R, M1F, ZN>(a, sb, L, mb, off);
+        adam_apply<ZC, R, HAS_MASK, M1F, ZN>(a, sa, L, m, off, av, mk, m1av, uacc, vbase, lane, ddd, dxx);
+        if (mb < m1e) {
+            if (ma < m1e) adam_load<ZC, R, M1F, ZN>(a, sa, L, ma, off);
+            adam_apply<ZC, R, HAS_MASK, M1F, ZN>(a, sb, L, mb, off, av, mk, m1av, uacc, vbase, lane, ddd, dxx);
+        }
+        m = ma;
+    }
+}
+
 template <int ZC, int R, bool HAS_MASK, bool M1F>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(const AdamArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
-    const int z0 = blockIdx.y * ZC;
-    const int zcnt = min(ZC, a.q.nZ - z0);
+    const int z0 = blockIdx.y * a.q.zs;   // z-chunks are balanced: zs = ceil(nZ / n_zchunks) <= ZC planes each
+    const int zcnt = min(min(a.q.zs, ZC), a.q.nZ - z0);
     const int gz = gridDim.z, bz = blockIdx.z;
     double ddd = 0, dxx = 0;
     const LaneMap<R> L(a.q, wt, lane);
@@ -591,19 +625,17 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
             f4 uacc[ZC];
 #pragma unroll
             for (int k = 0; k < ZC; ++k) uacc[k] = (f4){0.f, 0.f, 0.f, 0.f};
-            AdamSlab<ZC> sa, sb;   // ping-pong: one being updated, the other in flight
-            int m = m0;
-            if (m < m1e) adam_load<ZC, R, M1F>(a, sa, L, m, off, zcnt);
-            while (m < m1e) {
-                const int mb = m + gz, ma = mb + gz;
-                if (mb < m1e) adam_load<ZC, R, M1F>(a, sb, L, mb, off, zcnt);
-                adam_apply<ZC, R, HAS_MASK, M1F>(a, sa, L, m, off, zcnt, av, mk, m1av, uacc, vbase, lane, ddd, dxx);
-                if (mb < m1e) {
-                    if (ma < m1e) adam_load<ZC, R, M1F>(a, sa, L, ma, off, zcnt);
-                    adam_apply<ZC, R, HAS_MASK, M1F>(a, sb, L, mb, off, zcnt, av, mk, m1av, uacc, vbase, lane, ddd, dxx);
-                }
-                m = ma;
+#define DFX_ZN_CASE(n)                                                                                          \
+    case n:                                                                                                     \
+        if constexpr (n <= ZC)                                                                                  \
+            adam_chunk<ZC, R, HAS_MASK, M1F, n>(a, L, m0, m1e, gz, off, av, mk, m1av, uacc, vbase, lane, ddd, dxx); \
+        break;
+            switch (zcnt) {
+                DFX_ZN_CASE(1) DFX_ZN_CASE(2) DFX_ZN_CASE(3) DFX_ZN_CASE(4)
+                DFX_ZN_CASE(5) DFX_ZN_CASE(6) DFX_ZN_CASE(7) DFX_ZN_CASE(8)
+                default: break;
             }
+#undef DFX_ZN_CASE
             float *up = a.u_part + (long long)bz * a.q.S + off;
 #pragma unroll
             for (int k = 0; k < ZC; ++k) {
@@ -1148,7 +1180,8 @@ int check_plan(const Geo &q, const dfx_plan *pl) {
         if (!fast_ok(q)) return fail(DFX_EPLAN, "fast plan on a geometry that needs the generic path");
         if (pl->zc != 4 && pl->zc != 8) return fail(DFX_EPLAN, "fast plan: zc must be 4 or 8");
         if (pl->cpb <= 0 || pl->n_chunks % pl->cpb) return fail(DFX_EPLAN, "plan: n_chunks must be a multiple of cpb");
-        if ((long long)pl->zc * pl->n_zchunks < q.nZ || (long long)pl->steps * pl->n_chunks < q.M)
+        if (pl->zs <= 0 || pl->zs > pl->zc) return fail(DFX_EPLAN, "fast plan: need 0 < zs <= zc");
+        if ((long long)pl->zs * pl->n_zchunks < q.nZ || (long long)pl->steps * pl->n_chunks < q.M)
             return fail(DFX_EPLAN, "plan does not cover the geometry");
         if (pl->n_zchunks > 65535) return fail(DFX_EPLAN, "plan grid too large");
         const long long gz = (pl->n_chunks + pl->cpb - 1) / pl->cpb;
@@ -1227,19 +1260,29 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         int zc;
         // measured on MI355X at t256 x l16 x z16 x 128^2 (tools/tune_kernels.py): zc = 8 beats 16 (which
         // needs 256 VGPRs + AGPRs, and spills in the Adam kernel) by 5 % and 4 by 3 %: 16 is not built
-        // the slowest workgroups are those of the full z-chunks, so a ragged nZ costs its padded plane count:
-        // take the chunk size that pads least, 8 on a tie (nZ = 5..7 -> one chunk of 8; 10 -> 4 + 4 + 2; measured at
-        // t256 x l16 x z{5,6,10} x 128^2: sweep 1.29 vs 1.44, 1.41 vs 1.53, 2.48 vs 2.66 ms)
+        // z-chunks are balanced: n = ceil(nZ / ZC) chunks of zs = ceil(nZ / n) planes each, so every workgroup streams
+        // (almost) the same bytes; the inner loops are compiled for every live-plane count 1..ZC, so a chunk of
+        // zs < ZC planes costs only its unused registers.  Pick the ZC that pads nZ least, with a small preference
+        // for full register tiles; 8 on a tie.  nZ = 16 -> 8 + 8; 20 -> 5 x 4; 5 -> 5; 10 -> 5 + 5; 21 -> 7 + 7 + 7.
+        int zs;
         {
-            const int pad8 = (q.nZ + 7) / 8 * 8, pad4 = (q.nZ + 3) / 4 * 4;
-            zc = pad8 <= pad4 ? 8 : 4;
+            double best = 1e30;
+            zc = 8, zs = 8;
+            for (int cand = 8; cand >= 4; cand -= 4) {
+                const int n = (q.nZ + cand - 1) / cand, per = (q.nZ + n - 1) / n;
+                const double cost = (double)n * per / q.nZ * (1.0 + 0.05 * (cand - per) / cand);
+                if (cost < best - 1e-9) best = cost, zc = cand, zs = per;
+            }
         }
         if (zc_req) {
             if (zc_req != 4 && zc_req != 8) return fail(DFX_EINVAL, "zc must be 0 (auto), 4 or 8");
             zc = zc_req;
+            const int n = (q.nZ + zc - 1) / zc;
+            zs = (q.nZ + n - 1) / n;
         }
         out->zc = zc;
-        out->n_zchunks = (q.nZ + zc - 1) / zc;
+        out->zs = zs;
+        out->n_zchunks = (q.nZ + zs - 1) / zs;
         // Grid sizing.  Measured on MI355X (tools/tune_kernels.py): these kernels stream fastest with ONE
         // 4-wave workgroup per CU walking a long run of slabs (C2: 6.0 TB/s at 256 workgroups vs 5.5 at 2048:
         // fewer concurrent DRAM streams), so the default target is the CU count.  `steps` only sets how often
@@ -1264,7 +1307,9 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
             const long long gz_hi = (4LL * target_blocks + groups - 1) / groups;
             for (long long c = 1; c <= gz_hi && c <= n_chunks && c <= 65535; ++c) {
                 const long long nb = groups * c, rounds = (nb + target_blocks - 1) / target_blocks;
-                const double score = (double)nb / (double)(rounds * target_blocks) - 0.02 * (double)(rounds - 1);
+                // a second or third round of workgroups costs more than its fill suggests: 512 workgroups ran 5.7 %
+                // slower than 256 at C2 (more concurrent DRAM streams)
+                const double score = (double)nb / (double)(rounds * target_blocks) - 0.06 * (double)(rounds - 1);
                 if (score > best + 1e-9) best = score, gz = c;
             }
         }
@@ -1280,6 +1325,7 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
     } else {
         out->fast = 0;
         out->zc = 1;
+        out->zs = 1;
         out->n_zchunks = 1;
         out->steps = q.M;
         out->n_chunks = 1;
@@ -1306,6 +1352,7 @@ static int sweep_impl(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
+    q.zs = pl->fast ? pl->zs : 1;
     if (c_lo < 0 || c_hi > pl->cpb || c_lo >= c_hi || slice < 0 || slice >= DFX_MAX_SLICES)
         return fail(DFX_EINVAL, "dfx_sweep_chunks: need 0 <= c_lo < c_hi <= cpb and 0 <= slice < DFX_MAX_SLICES");
     if (!pl->fast && (c_lo != 0 || c_hi != pl->cpb || slice != 0 || !last))
@@ -1408,6 +1455,7 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
+    q.zs = pl->fast ? pl->zs : 1;
     if (!out || !A || !B || !scal || !part) return fail(DFX_EINVAL, "dfx_bcast: NULL buffer");
     hipStream_t st = (hipStream_t)stream;
     BcastArgs a{out, in, A, B, mask, coef_dev, part, sa, sb, coef_host, q, pl->steps, pl->n_chunks, pl->cpb};
@@ -1438,6 +1486,7 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
+    q.zs = pl->fast ? pl->zs : 1;
     const bool m1f = (m1 == nullptr);
     if (!x || !m2 || !A || !B || !scal || !u_part || !v_part || !part || (m1f && (!m1a || !m1b)))
         return fail(DFX_EINVAL, "dfx_adam_step: NULL buffer");
@@ -1510,6 +1559,7 @@ int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, flo
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
+    q.zs = pl->fast ? pl->zs : 1;
     if (!u_part || !u || !scal || !part) return fail(DFX_EINVAL, "dfx_reduce_u: NULL buffer");
     hipStream_t st = (hipStream_t)stream;
     const int nb = ew_blocks(q.S, 1);
@@ -1523,6 +1573,7 @@ int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, flo
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
+    q.zs = pl->fast ? pl->zs : 1;
     if (!v_part || !v) return fail(DFX_EINVAL, "dfx_reduce_v: NULL buffer");
     if (m_lo < 0 || m_hi > q.M || m_lo >= m_hi) return fail(DFX_EINVAL, "dfx_reduce_v: bad slab range");
     const long long len = (long long)q.M * q.Ps;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 111
+#define DFX_VERSION 112
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -42,12 +42,12 @@ typedef struct dfx_geom {
 typedef struct dfx_plan {
     int32_t fast;
     int32_t zc;          /* z planes a workgroup keeps in registers */
-    int32_t n_zchunks;   /* ceil(nZ / zc) */
+    int32_t n_zchunks;   /* ceil(nZ / zs) */
     int32_t steps;       /* (t,lambda) slabs per u_part chunk (flush interval of the fp32 u sums) */
     int32_t n_chunks;    /* ceil(nT*nL / steps) */
     int32_t cpb;         /* consecutive chunks one workgroup walks through */
     int32_t n_blocks;    /* workgroups per sweep / bcast launch */
-    int32_t pad_;
+    int32_t zs;          /* planes per z-chunk: ceil(nZ / n_zchunks) <= zc (chunks are balanced) */
     int64_t u_part_elems;    /* floats: (n_chunks / cpb) * nZ*X*Y: one row per workgroup of the slab axis */
     int64_t v_part_elems;    /* floats: n_zchunks * nT*nL*Xs*Ys */
     int64_t part_elems;      /* doubles: max(n_blocks * DFX_MAX_SLICES, DFX_EW_MAXBLOCKS) * DFX_NPART */

@@ -114,7 +114,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libdfx.so does not export {n}"
-    assert cabi.lib().dfx_version() == 111
+    assert cabi.lib().dfx_version() == 112
 
 
 def test_header_constants_match_python_mirror():
@@ -143,8 +143,8 @@ def test_planner_covers_geometry(dims, fast):
     n_t, n_l, n_z, X, Y, r = dims
     assert p.fast == fast
     if fast:
-        assert p.zc * p.n_zchunks >= n_z and p.steps * p.n_chunks >= n_t * n_l
-        assert (p.n_zchunks - 1) * p.zc < n_z
+        assert 0 < p.zs <= p.zc and p.zs * p.n_zchunks >= n_z and p.steps * p.n_chunks >= n_t * n_l
+        assert (p.n_zchunks - 1) * p.zs < n_z and p.n_zchunks * p.zs - n_z < p.n_zchunks      # balanced chunks
     else:
         assert p.n_chunks == 1 and p.n_zchunks == 1
     assert p.u_part_elems == (p.n_chunks // max(p.cpb, 1)) * n_z * X * Y
@@ -353,3 +353,13 @@ def test_sweep_slice_bounds_decrease_and_cover():
             d = [b[i + 1] - b[i] for i in range(k)]
             assert b[0] == 0 and b[-1] == cpb and len(b) == k + 1 and min(d) >= 1
             assert d[-1] == min(d)
+
+
+@pytest.mark.parametrize("n_z,expect", [(16, (8, 8, 2)), (20, (4, 4, 5)), (5, (8, 5, 1)), (10, (8, 5, 2)), (21, (8, 7, 3)),
+                                        (9, (4, 3, 3)), (4, (4, 4, 1)), (1, (4, 1, 1)), (32, (8, 8, 4))])
+def test_planner_balances_z_chunks(n_z, expect):
+    """(zc, zs, n_zchunks): chunks of equal size zs = ceil(nZ / n) so that every workgroup streams the same bytes."""
+    from datafusion_amd import _cabi as cabi
+    g, p = cabi.Geom(8, 4, n_z, 32, 32, 4, 0), cabi.Plan()
+    assert cabi.lib().dfx_plan_make(C.byref(g), 0, C.byref(p)) == 0
+    assert (p.zc, p.zs, p.n_zchunks) == expect
