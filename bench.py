@@ -205,6 +205,7 @@ def main():
                "sweep_bytes": sweep_words * 4 * f.k.N,
                "iter_words": sweep_words + (3 if a.no_defer else 0) + (0 if fact else 2),   # + dfx_axpy, + dfx_bcast
                "launches": len(timing[sweep_name]) // a.steps, "zc": f.k.plan.zc, "n_local": f.k.N,
+               "pair_probe": getattr(f.k, "pair_probe", None),
                "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "cpb", "n_blocks")}}
         del f
         torch.cuda.empty_cache()
@@ -251,7 +252,8 @@ def main():
                                        "configs[1] volume at 1 GPU; iters_per_s is the iteration rate of the whole "
                                        "sharded volume", "x_update": "textbook" if a.no_defer else "deferred",
                    "residual": a.residual, "words_moved_per_iteration": f"{main_res['iter_words']} N",
-                   "sweep_launches_per_iteration": main_res["launches"], "plan": main_res["plan"]},
+                   "sweep_launches_per_iteration": main_res["launches"], "plan": main_res["plan"],
+                   "placement_probe_GBps": main_res["pair_probe"]},
         # whole iteration, all GPUs: SURVEY 8(d) prices an iteration at 32 N bytes and asks for that basis to be quoted
         # as "effective"; the build moves fewer (16 N with the factored residual), so "effective" may exceed the peak:
         # the honest bandwidth figure is hbm_moved_GBps and the per-kernel roofline below

@@ -76,7 +76,8 @@ class Fusion:
 
     def __init__(self, spc, cmos, *, weights: dict, init_type: str, tol: float | None = 3e-3,
                  mask_noise: bool = False, total_energy: float = 1.0, device: str = "cuda", seed: int = 42,
-                 verbose: bool = False, group=None, defer_x: bool = True, target_blocks: int = 0):
+                 verbose: bool = False, group=None, defer_x: bool = True, target_blocks: int = 0,
+                 placement_tries: int = 6):
         dev = torch.device(device)
         self.spc = self._to_device(spc, "spc", dev)      # fusion.py:135-148
         self.cmos = self._to_device(cmos, "cmos", dev)
@@ -98,6 +99,7 @@ class Fusion:
         if r < 1 or self.cmos.shape[1] != r * self.spc.shape[2] or self.cmos.shape[2] != r * self.spc.shape[3]:
             raise ValueError("cmos (z, x, y) must be an integer multiple r of spc (t, l, x/r, y/r) in x and y")
         self.defer_x = bool(defer_x) and not verbose
+        self.placement_tries = int(placement_tries)   # HipKernels.new_vector_paired: large vectors only
 
         self.T = SumOperator(size=self.n_times, integral_dim=0)        # fusion.py:172-179
         self.S = SumOperator(size=self.n_lambdas, integral_dim=1)
@@ -318,7 +320,7 @@ class FusionCG(Fusion):
         c1, c2 = self._coefs()
         fact = self.residual == "factored"
         if self._p is None:
-            self._p = k.new_vector()
+            self._p = k.new_vector_paired(self.x, self.placement_tries)
             if fact:
                 k.new_factored_residual()
             else:
@@ -448,7 +450,7 @@ class FusionAdam(Fusion):
         self.fused = fused
         self.moment1 = moment1
         self.betas, self.adam_eps = betas, adam_eps
-        self._m1 = self._m2 = None
+        self._m1 = self._m2 = self._m1a = self._m1b = None
         self._adam_step = 0
 
     def loss_autograd(self, mask_grad: bool = False):
@@ -471,10 +473,14 @@ class FusionAdam(Fusion):
         x = self.x.data
         # a fresh optimizer per call, like fusion.py:325
         fact = self.moment1 == "factored"
-        self._m1 = None if fact else torch.zeros_like(x)
-        self._m1a = torch.zeros_like(k.u) if fact else None
-        self._m1b = torch.zeros_like(k.v) if fact else None
-        self._m2 = torch.zeros_like(x)
+        if self._m2 is None:                       # buffers are kept for later calls (state is reset below)
+            self._m2 = k.new_vector_paired(x, self.placement_tries)
+            self._m1 = None if fact else torch.empty_like(x)
+            self._m1a = torch.empty_like(k.u) if fact else None
+            self._m1b = torch.empty_like(k.v) if fact else None
+        for t in (self._m1, self._m1a, self._m1b, self._m2):
+            if t is not None:
+                t.zero_()
         self._adam_step = 0
         self._project(x)                                   # u(x), v(x) for the first loss / gradient
         for i in range(max_iterations):

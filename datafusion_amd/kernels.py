@@ -106,6 +106,59 @@ class HipKernels:
         bounds[-1] = cpb
         return bounds
 
+    # vectors at least this large are placed with a probe (see new_vector_paired)
+    PAIR_PROBE_MIN_BYTES = 8 << 30
+    HBM_PEAK_BYTES_PER_S = 8.0e12      # MI355X (gfx950), the only target of this build
+
+    def new_vector_paired(self, ref: torch.Tensor, tries: int = 6) -> torch.Tensor:
+        """A new 5-D vector that streams well TOGETHER with `ref`.
+
+        On MI355X two large vectors swept in lock-step run at 6.4 TB/s when they lie in different regions of device
+        memory and at 5.3 TB/s when they share one (tools/placement_probe.py, DESIGN.md "placement"); which region an
+        allocation lands in is the driver's choice.  So for vectors of PAIR_PROBE_MIN_BYTES or more, up to `tries`
+        candidates are allocated (the rejected ones are held until the choice is made, otherwise the driver hands
+        the same memory out again), each is timed against `ref` with the real pass run as a no-op, and the fastest is
+        kept.  Stops as soon as both regimes have been seen."""
+        nbytes = 4 * self.N
+        if tries <= 1 or nbytes < self.PAIR_PROBE_MIN_BYTES:
+            return self.new_vector()
+        # the probe is the real pass: the factored XP sweep with alpha = beta = 0 over zeroed residual factors and a
+        # zeroed candidate (x += 0 * 0 leaves ref as it is; the candidate stays zero)
+        had_factors = self.ra is not None
+        self.new_factored_residual()
+        saved = (self.ra.clone(), self.rb.clone(), self.scal.clone()) if had_factors else None
+        self.ra.zero_(), self.rb.zero_()
+        self.scal[cabi.S_ALPHA], self.scal[cabi.S_BETA] = 0.0, 0.0
+        cands, rates = [], []
+        for i in range(tries):
+            if i and torch.cuda.mem_get_info(self.device)[0] < nbytes + (2 << 30):
+                break
+            v = self.new_vector().zero_()
+            best = 1e30
+            for _ in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.device))
+                self.sweep(cabi.SWEEP_XP, ref, None, v, factored=True)
+                e1.record(torch.cuda.current_stream(self.device))
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            cands.append(v)
+            rates.append(4.0 * nbytes / best)
+            # done once both regimes have been seen, or when this candidate is clearly in the good one
+            # (MI355X: ~6.3 TB/s vs ~5.3 TB/s, i.e. 0.79 vs 0.66 of the 8 TB/s peak)
+            if max(rates) >= 1.08 * min(rates) or rates[-1] * 1e3 >= 0.72 * self.HBM_PEAK_BYTES_PER_S:
+                break
+        if saved is not None:
+            self.ra.copy_(saved[0]), self.rb.copy_(saved[1]), self.scal.copy_(saved[2])
+        else:
+            self.scal.zero_()
+            self.ra = self.rb = self.zab = None
+        keep = cands[max(range(len(cands)), key=rates.__getitem__)]
+        self.pair_probe = [r / 1e6 for r in rates]            # GB/s of every candidate, for logs and tests
+        del cands, v
+        torch.cuda.empty_cache()
+        return keep
+
     def _chk(self, *ts):
         for t in ts:
             if t is not None:

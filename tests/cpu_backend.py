@@ -48,6 +48,9 @@ class CpuStandIn:
         out = torch.tensor(coef, dtype=torch.float32) * (a - b)
         return out * mask if mask is not None else out
 
+    def new_vector_paired(self, ref, tries=3):
+        return self.new_vector()
+
     def new_vector(self):
         return torch.empty(self.shape)
 

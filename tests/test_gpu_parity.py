@@ -445,3 +445,25 @@ def test_cg_verbose_history_with_masks_matches_reference(golden):
     h, hr = f.history, g["hist"]
     assert np.allclose(h[:5, :3], hr[:5, :3], rtol=2e-3, atol=1e-12)
     assert np.allclose(h[:3, 3], hr[:3, 3], rtol=2e-3)
+
+
+def test_placement_probe_leaves_the_solve_unchanged(golden, monkeypatch):
+    """HipKernels.new_vector_paired (used for vectors >= 8 GiB) forced on at a small shape: the probe sweeps are
+    no-ops on x, state it borrows is restored, and the solve gives the golden result."""
+    from datafusion_amd import FusionAdam, FusionCG
+    from datafusion_amd.kernels import HipKernels
+    monkeypatch.setattr(HipKernels, "PAIR_PROBE_MIN_BYTES", 0)
+    g = golden("cg_t8l4z4_32_r4")
+    f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, placement_tries=3)
+    x0 = f.x.clone()
+    f.start()
+    assert torch.equal(f.x, x0) and 1 <= len(f.k.pair_probe) <= 3
+    f.iterate(20)
+    f.finish()
+    assert O.rel_l2(f.x.cpu(), g["x_20"]) <= TIGHT
+    x, _, _ = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV)(20)
+    assert np.array_equal(f.x.cpu().numpy(), x)            # bit-identical to a solve without the probe
+    g = golden("adam_t6l4z3_32")
+    fa = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, placement_tries=2)
+    xa, _, _ = fa(lr=float(g["lr"]), max_iterations=5)
+    assert O.rel_l2(xa, g["x_5"]) <= TIGHT

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--arena-gib", type=int, default=0,
                     help="instead: ONE allocation of this size; x and p are windows sliding through it (--stride-gib)")
     ap.add_argument("--stride-gib", type=float, default=4.0)
+    ap.add_argument("--delta-scan", action="store_true", help="arena mode: keep x fixed, move p")
+    ap.add_argument("--x-gib", type=float, default=0.0)
     a = ap.parse_args()
     shape = tuple(int(v) for v in a.shape.split(","))
     k = HipKernels(*shape, 4, "cuda:0")
@@ -47,9 +49,34 @@ def main():
     if a.arena_gib:
         arena = torch.zeros(a.arena_gib << 28, device="cuda:0")          # floats
         stride = int(a.stride_gib * (1 << 28))
+        if a.delta_scan:
+            # x fixed at the start of the arena (or --x-gib), p at every stride further on: does the DISTANCE matter?
+            x0 = int(a.x_gib * (1 << 28))
+            x = arena[x0:x0 + k.N].view(k.shape)
+            d = k.N
+            while x0 + d + k.N <= arena.numel():
+                p = arena[x0 + d:x0 + d + k.N].view(k.shape)
+                ms = time_sweep(k, x, p, a.reps)
+                print(f"x at {a.x_gib:5.1f} GiB, p {d / (1 << 28):6.2f} GiB behind: sweep {ms:.3f} ms = "
+                      f"{4 * nbytes / ms / 1e6:.0f} GB/s", flush=True)
+                d += stride
+            return
         off = 0
         while off + 2 * k.N <= arena.numel():
             x = arena[off:off + k.N].view(k.shape)
+            # one vector alone: read-only projection, and read + write in place (x += 0 * x)
+            best_r = best_rw = 1e9
+            for _ in range(a.reps):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record()
+                k.sweep(cabi.SWEEP_PROJECT, x)
+                e[1].record()
+                k.axpy(x, x, 0.0, None)
+                e[2].record()
+                torch.cuda.synchronize()
+                best_r, best_rw = min(best_r, e[0].elapsed_time(e[1])), min(best_rw, e[1].elapsed_time(e[2]))
+            print(f"arena offset {off / (1 << 28):6.1f} GiB x alone: read {nbytes / best_r / 1e6:.0f} GB/s, "
+                  f"read+write {2 * nbytes / best_rw / 1e6:.0f} GB/s", flush=True)
             for gap in (0, 1 << 20):                                      # p right behind x, and 4 MiB further
                 if off + 2 * k.N + gap > arena.numel():
                     continue
