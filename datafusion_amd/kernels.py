@@ -145,8 +145,8 @@ class HipKernels:
             cands.append(v)
             rates.append(4.0 * nbytes / best)
             # done once both regimes have been seen, or when this candidate is clearly in the good one
-            # (MI355X: ~6.3 TB/s vs ~5.3 TB/s, i.e. 0.79 vs 0.66 of the 8 TB/s peak)
-            if max(rates) >= 1.08 * min(rates) or rates[-1] * 1e3 >= 0.72 * self.HBM_PEAK_BYTES_PER_S:
+            # (MI355X: ~6.3 TB/s vs ~5.3 TB/s, i.e. 0.79 vs 0.66 of the 8 TB/s peak; mixed placements fall in between)
+            if max(rates) >= 1.08 * min(rates) or rates[-1] * 1e3 >= 0.76 * self.HBM_PEAK_BYTES_PER_S:
                 break
         if saved is not None:
             self.ra.copy_(saved[0]), self.rb.copy_(saved[1]), self.scal.copy_(saved[2])
