@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 
 import torch
 
@@ -107,7 +108,7 @@ class HipKernels:
         return bounds
 
     # vectors at least this large are placed with a probe (see new_vector_paired)
-    PAIR_PROBE_MIN_BYTES = 8 << 30
+    PAIR_PROBE_MIN_BYTES = int(os.environ.get("DFX_PAIR_PROBE_MIN_BYTES", 8 << 30))
     HBM_PEAK_BYTES_PER_S = 8.0e12      # MI355X (gfx950), the only target of this build
 
     def new_vector_paired(self, ref: torch.Tensor, tries: int = 6) -> torch.Tensor:
