@@ -89,7 +89,8 @@ enum {
 int dfx_version(void);
 const char *dfx_last_error(void);
 
-/* Choose the launch plan and workspace sizes.  target_blocks <= 0 -> default (one workgroup per CU of the
+/* (No counterpart in the reference, which is eager ATen: launch geometry and workspace sizes are this library's.)
+ * Choose the launch plan and workspace sizes.  target_blocks <= 0 -> default (one workgroup per CU of the
  * current device; 256 when no device is visible). */
 int dfx_plan_make(const dfx_geom *g, int32_t target_blocks, dfx_plan *out);
 /* Same with overrides for tuning: zc in {0 = auto, 4, 8}, steps (0 = auto). */
@@ -103,7 +104,7 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc, int32
 int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
               double *scal, float *u_part, float *v_part, double *part, void *stream);
 
-/* The same sweep cut along the slab axis, for overlapping the cross-shard sum of v with the rest of the sweep:
+/* The same sweep (same reference lines as dfx_sweep: fusion.py:44-51,89-98,423-426,445,455) cut along the slab axis, for overlapping the cross-shard sum of v with the rest of the sweep:
  * launch `slice` (0, 1, ...) handles chunks [c_lo, c_hi) of the plan's cpb, i.e. the contiguous slabs
  * [c_lo*steps*gz, min(c_hi*steps*gz, nT*nL)) with gz = n_chunks / cpb; when it has run, those rows of v_part
  * are final.  Slices must be issued in order with increasing `slice`; `last` != 0 on the final one folds the
@@ -151,7 +152,8 @@ int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, fl
                   const float *B, const float *mask, double lr, double beta1, double beta2, double eps, int32_t step,
                   int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream);
 
-/* The same step with the FIRST moment kept in factored form.  exp_avg is linear in the gradients and every gradient
+/* The same step (optimizer.step() of fusion.py:340 with the Adam of fusion.py:325) with the FIRST moment kept in
+ * factored form.  exp_avg is linear in the gradients and every gradient
  * is mask * (A[z,x,y] + B[t,l,x/r,y/r]), so m1 = mask * (m1a[z,x,y] + m1b[t,l,x/r,y/r]) exactly and the 5-D m1 array
  * never exists: the caller advances the factors with dfx_lerp(m1a, A, 1-beta1), dfx_lerp(m1b, B, 1-beta1) (torch's
  * exp_avg.lerp_) BEFORE this call; x and m2 are read and written (4N words instead of 6N).  No counterpart for m2:
@@ -160,16 +162,19 @@ int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, cons
                            float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
                            double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
                            float *v_part, double *part, void *stream);
-/* m[i] += (float)weight * (g[i] - m[i]), i < n  (torch.lerp_ as torch.optim.Adam applies it to exp_avg). */
+/* m[i] += (float)weight * (g[i] - m[i]), i < n  (torch.lerp_ as torch.optim.Adam applies it to exp_avg inside
+ * optimizer.step(), fusion.py:340). */
 int dfx_lerp(float *m, const float *g, int64_t n, double weight, void *stream);
 
-/* u[i] = sum over the n_chunks/cpb rows of u_part[row][i] (i < nZ*X*Y); scal[DFX_S_UU] = sum u^2. */
+/* u[i] = sum over the n_chunks/cpb rows of u_part[row][i] (i < nZ*X*Y); scal[DFX_S_UU] = sum u^2: the last stage of
+ * the T and S sums of fusion.py:44-51 and the ST part of torch.dot(p, Ap), fusion.py:444. */
 int dfx_reduce_u(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, double *scal,
                  double *part, void *stream);
-/* v[m] = sum_zc v_part[zc][m] for the slabs m_lo <= m < m_hi (rows of Xs*Ys floats). */
+/* v[m] = sum_zc v_part[zc][m] for the slabs m_lo <= m < m_hi (rows of Xs*Ys floats): the last stage of the D sum of
+ * fusion.py:44-51 feeding R, fusion.py:89-98. */
 int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, float *v, int64_t m_lo, int64_t m_hi,
                  void *stream);
-/* scal[slot] = sum_i a[i]^2. */
+/* scal[slot] = sum_i a[i]^2  (||v(p)||^2: the RD part of torch.dot(p, Ap), fusion.py:444). */
 int dfx_sqnorm(const float *a, int64_t n, double *scal, int32_t slot, double *part, void *stream);
 /* scal[slot] = w * sum_i mask[i % mask_n] * (a[i] - b[i])^2, mask optional (loss terms,
  * fusion.py:216-232; squared_l2 fusion.py:12-18). */
