@@ -467,3 +467,18 @@ def test_placement_probe_leaves_the_solve_unchanged(golden, monkeypatch):
     fa = FusionAdam(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, placement_tries=2)
     xa, _, _ = fa(lr=float(g["lr"]), max_iterations=5)
     assert O.rel_l2(xa, g["x_5"]) <= TIGHT
+
+
+@pytest.mark.parametrize("w", [{"spatial": 0.0, "spectro_temporal": 1.0}, {"spatial": 1.0, "spectro_temporal": 0.0},
+                               {"spatial": 3.0, "spectro_temporal": 0.25}])
+def test_cg_degenerate_and_unnormalised_weights_vs_oracle(w):
+    """One term switched off (c1 = 0 or c2 = 0: one residual factor stays zero, no gauge to balance) and weights that
+    do not sum to one."""
+    from datafusion_amd import FusionCG
+    spc, cmos = O.cells_like_inputs(6, 4, 5, 32, 4, seed=21)
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
+    xo = O.cg(pb, 8, with_loss=False)
+    for residual in ("factored", "explicit"):
+        f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV, residual=residual)
+        x, _, _ = f(8)
+        assert O.rel_l2(x, xo) <= TIGHT, (w, residual)
