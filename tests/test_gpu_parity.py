@@ -482,3 +482,21 @@ def test_cg_degenerate_and_unnormalised_weights_vs_oracle(w):
         f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV, residual=residual)
         x, _, _ = f(8)
         assert O.rel_l2(x, xo) <= TIGHT, (w, residual)
+
+
+def test_inputs_as_tensors_of_other_dtypes_and_devices(golden):
+    """fusion.py:135-148: numpy arrays or torch tensors; anything is converted to float32 on the device."""
+    from datafusion_amd import FusionCG
+    g = golden("cg_t6l5z3_24_r4")
+    ref, _, _ = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV)(5)
+    variants = [
+        (torch.from_numpy(g["spc"]), torch.from_numpy(g["cmos"])),                               # CPU float64 tensors
+        (torch.from_numpy(g["spc"]).float().to(DEV), torch.from_numpy(g["cmos"]).float().to(DEV)),  # already on the GPU
+        (g["spc"].astype(np.float32), np.asfortranarray(g["cmos"])),                             # float32 / F-ordered
+    ]
+    for spc, cmos in variants:
+        x, spc_n, cmos_n = FusionCG(spc, cmos, weights=W(g), init_type="baseline", tol=None, device=DEV)(5)
+        assert np.array_equal(x, ref) and spc_n.dtype == np.float32 and cmos_n.dtype == np.float32
+    xt, st, ct = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV)(
+        5, return_numpy=False)
+    assert isinstance(xt, torch.Tensor) and xt.device.type == "cuda" and np.array_equal(xt.cpu().numpy(), ref)
