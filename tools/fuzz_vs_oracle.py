@@ -1,0 +1,65 @@
+"""Random small geometries: FusionCG (factored and explicit residual, deferred and textbook x update) and FusionAdam
+(factored and explicit first moment) against the CPU oracle.  Not part of the test-suite (takes a minute); run on a
+GPU box after touching the lane mapping, the z-chunk dispatch or the planner.
+
+    python tools/fuzz_vs_oracle.py [--cases 40] [--seed 0]
+"""
+import argparse
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from datafusion_amd import FusionAdam, FusionCG  # noqa: E402
+from oracle import fusion_oracle as O  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    worst = 0.0
+    for case in range(a.cases):
+        r = rng.choice([2, 4, 4, 4, 8, 3])
+        xs = rng.randint(1, 64 // r)
+        n_t, n_l, n_z = rng.randint(1, 12), rng.randint(1, 7), rng.randint(1, 19)
+        xy = xs * r
+        w = {"spatial": rng.choice([0.5, 0.2, 0.8]), "spectro_temporal": rng.choice([0.5, 0.8, 0.2])}
+        mask = rng.random() < 0.3
+        gen = O.cells_like_inputs if rng.random() < 0.5 else O.synthetic_inputs
+        spc, cmos = gen(n_t, n_l, n_z, xy, r, seed=case)
+        iters = rng.randint(1, 7)
+        pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None, mask_noise=mask)
+        xo = O.cg(pb, iters, with_loss=False)
+        errs = {}
+        for residual in ("factored", "explicit"):
+            for defer in (True, False):
+                f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device="cuda:0", residual=residual,
+                             defer_x=defer, mask_noise=mask)
+                x, _, _ = f(iters)
+                errs[f"cg/{residual}/{'defer' if defer else 'textbook'}"] = O.rel_l2(x, xo)
+        pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None, mask_noise=mask)
+        # Adam moves every element by ~lr per step whatever the gradient's size: keep the step small against the
+        # mean of x (1 / N), otherwise elements whose gradient is zero up to rounding dominate the comparison
+        lr = 1e-2 / (n_t * n_l * n_z * xy * xy)
+        xa = O.adam(pb, lr, 3, non_neg=mask)
+        for m1 in ("factored", "explicit"):
+            f = FusionAdam(spc, cmos, weights=w, init_type="baseline", tol=None, device="cuda:0", moment1=m1,
+                           mask_noise=mask)
+            x, _, _ = f(lr=lr, max_iterations=3, non_neg=mask)
+            errs[f"adam/{m1}"] = O.rel_l2(x, xa)
+        bad = {k: v for k, v in errs.items() if not v <= 2e-5}
+        worst = max(worst, max(errs.values()))
+        print(f"case {case}: t{n_t} l{n_l} z{n_z} {xy}x{xy} r{r} mask={mask} iters={iters} fast={f.k.plan.fast} "
+              f"zc={f.k.plan.zc}/{f.k.plan.zs} max err {max(errs.values()):.2e}" + (f"  FAIL {bad}" if bad else ""),
+              flush=True)
+        assert not bad, bad
+    print(f"{a.cases} cases, worst rel-L2 vs the oracle {worst:.3e}")
+
+
+if __name__ == "__main__":
+    main()
