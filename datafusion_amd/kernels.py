@@ -127,7 +127,8 @@ class HipKernels:
         # zeroed candidate (x += 0 * 0 leaves ref as it is; the candidate stays zero)
         had_factors = self.ra is not None
         self.new_factored_residual()
-        saved = (self.ra.clone(), self.rb.clone(), self.scal.clone()) if had_factors else None
+        saved = (self.ra.clone(), self.rb.clone()) if had_factors else None
+        saved_scal = self.scal.clone()
         self.ra.zero_(), self.rb.zero_()
         self.scal[cabi.S_ALPHA], self.scal[cabi.S_BETA] = 0.0, 0.0
         cands, rates = [], []
@@ -149,10 +150,10 @@ class HipKernels:
             # (MI355X: ~6.3 TB/s vs ~5.3 TB/s, i.e. 0.79 vs 0.66 of the 8 TB/s peak; mixed placements fall in between)
             if max(rates) >= 1.08 * min(rates) or rates[-1] * 1e3 >= 0.76 * self.HBM_PEAK_BYTES_PER_S:
                 break
+        self.scal.copy_(saved_scal)
         if saved is not None:
-            self.ra.copy_(saved[0]), self.rb.copy_(saved[1]), self.scal.copy_(saved[2])
+            self.ra.copy_(saved[0]), self.rb.copy_(saved[1])
         else:
-            self.scal.zero_()
             self.ra = self.rb = self.zab = None
         keep = cands[max(range(len(cands)), key=rates.__getitem__)]
         self.pair_probe = [r / 1e6 for r in rates]            # GB/s of every candidate, for logs and tests
