@@ -23,11 +23,12 @@ def main():
     ap.add_argument("--shape", default="512,32,16,256")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--residual", default="factored", choices=["factored", "explicit"])
+    ap.add_argument("--cells", action="store_true", help="cells-like inputs (blobs x decays x spectra) instead of uniform")
     a = ap.parse_args()
     n_t, n_l, n_z, xy = map(int, a.shape.split(","))
     r, dev = 4, "cuda:0"
     w = {"spatial": 0.5, "spectro_temporal": 0.5}
-    spc, cmos = O.synthetic_inputs(n_t, n_l, n_z, xy, r)
+    spc, cmos = (O.cells_like_inputs if a.cells else O.synthetic_inputs)(n_t, n_l, n_z, xy, r)
     t0 = time.time()
     f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=dev, residual=a.residual)
     f._project(f.x)
@@ -56,6 +57,7 @@ def main():
         den += (ref ** 2).sum()
     err = float(torch.sqrt(num / den))
     out = {"shape": [n_t, n_l, n_z, xy, xy], "n_elements": f.k.N, "iterations": a.iters, "residual": a.residual,
+           "inputs": "cells-like" if a.cells else "uniform",
            "rel_l2_vs_fp64_collapsed": err, "rsnew_gpu": rs_gpu, "rsnew_fp64": rs[-1], "alpha_last_fp64": alphas[-1],
            "alpha_last_gpu": float(f.k.scal[3])}
     print(json.dumps(out), flush=True)
