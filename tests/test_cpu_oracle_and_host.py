@@ -363,3 +363,24 @@ def test_planner_balances_z_chunks(n_z, expect):
     g, p = cabi.Geom(8, 4, n_z, 32, 32, 4, 0), cabi.Plan()
     assert cabi.lib().dfx_plan_make(C.byref(g), 0, C.byref(p)) == 0
     assert (p.zc, p.zs, p.n_zchunks) == expect
+
+
+def test_header_is_plain_c_and_library_links_from_c(tmp_path):
+    """include/dfx.h must be usable from C (the drop-in boundary is a C ABI): compile a C99 program against it with
+    -pedantic, link libdfx.so, run the host-only planner."""
+    import shutil
+    import subprocess
+    from datafusion_amd import _cabi as cabi
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "dfx.h"\n'
+                   "int main(void) { dfx_geom g = {2, 3, 5, 8, 12, 4, 0}; dfx_plan p;\n"
+                   "  if (dfx_version() != DFX_VERSION) return 2;\n"
+                   "  if (dfx_plan_make(&g, 0, &p) != 0) return 3;\n"
+                   "  return (p.fast == 1 && p.zs * p.n_zchunks >= 5 && dfx_last_error() != 0) ? 0 : 4; }\n")
+    lib_dir = os.path.dirname(cabi.LIB_PATH)
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), "-L", lib_dir, "-ldfx", f"-Wl,-rpath,{lib_dir}"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
