@@ -193,3 +193,13 @@ def test_bench_prints_one_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
     assert d["config"]["residual"] == "factored" and d["other_residual_mode"]["residual"] == "explicit"
+
+
+def test_c_abi_without_python_or_torch():
+    """tests/native/cabi_standalone.cpp (built by __graft_entry__.build()): the ABI driven from C++ with nothing but
+    the HIP runtime - projection and a factored XP sweep checked against host loops."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "native", "cabi_standalone")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert p.returncode == 0 and "cabi_standalone: OK" in p.stdout, p.stdout + p.stderr
