@@ -313,14 +313,23 @@ class FusionCG(Fusion):
         n_t, n_l, n_z, r = self.n_times, self.n_lambdas, self.z_dim, self.spatial_increase
         return float(self.w1) / (n_t * n_l), float(self.w2) / (n_z * r * r)
 
+    def _placement_tries(self, planned_iterations) -> int:
+        """Placing a large vector by measurement (HipKernels.new_vector_paired) costs 0.1 - 0.3 s of allocations and
+        probe sweeps: worth it only when enough iterations follow.  Vectors >= 8 GiB gain ~19 % per iteration (probe
+        from 30 planned iterations on, or when the count is unknown); 1 - 8 GiB vectors gain 1.5 - 3 % (from 300)."""
+        big = 4 * self.k.N >= (8 << 30)
+        if planned_iterations is None:
+            return self.placement_tries if big else 1
+        return self.placement_tries if planned_iterations >= (30 if big else 300) else 1
+
     @torch.no_grad()
-    def start(self) -> None:
+    def start(self, planned_iterations: int | None = None) -> None:
         """r0 = b - A(x0), p0 = r0, rsold (fusion.py:428-437), from the current self.x."""
         k, c = self.k, self.comm
         c1, c2 = self._coefs()
         fact = self.residual == "factored"
         if self._p is None:
-            self._p = k.new_vector_paired(self.x, self.placement_tries)
+            self._p = k.new_vector_paired(self.x, self._placement_tries(planned_iterations))
             if fact:
                 k.new_factored_residual()
             else:
@@ -393,7 +402,7 @@ class FusionCG(Fusion):
     @torch.no_grad()
     def __call__(self, max_iterations: int, eps: float = 1e-10, return_numpy: bool = True):
         history = np.zeros((int(max_iterations), len(self.weights) + 2)) if self.verbose else None
-        self.start()
+        self.start(planned_iterations=int(max_iterations))
         self.iterate(max_iterations, eps, history)
         self.finish()
         self.history = history
@@ -474,7 +483,8 @@ class FusionAdam(Fusion):
         # a fresh optimizer per call, like fusion.py:325
         fact = self.moment1 == "factored"
         if self._m2 is None:                       # buffers are kept for later calls (state is reset below)
-            self._m2 = k.new_vector_paired(x, self.placement_tries)
+            big = 4 * k.N >= (8 << 30)      # the sweep-based probe did not help Adam below that (C2: 331 vs 331 it/s)
+            self._m2 = k.new_vector_paired(x, self.placement_tries if big and max_iterations >= 30 else 1)
             self._m1 = None if fact else torch.empty_like(x)
             self._m1a = torch.empty_like(k.u) if fact else None
             self._m1b = torch.empty_like(k.v) if fact else None

@@ -108,7 +108,8 @@ class HipKernels:
         return bounds
 
     # vectors at least this large are placed with a probe (see new_vector_paired)
-    PAIR_PROBE_MIN_BYTES = int(os.environ.get("DFX_PAIR_PROBE_MIN_BYTES", 8 << 30))
+    PAIR_PROBE_MIN_BYTES = int(os.environ.get("DFX_PAIR_PROBE_MIN_BYTES", 1 << 30))
+    PAIR_PROBE_BIG_BYTES = 8 << 30
     HBM_PEAK_BYTES_PER_S = 8.0e12      # MI355X (gfx950), the only target of this build
 
     def new_vector_paired(self, ref: torch.Tensor, tries: int = 6) -> torch.Tensor:
@@ -116,13 +117,19 @@ class HipKernels:
 
         On MI355X two large vectors swept in lock-step run at 6.4 TB/s when they lie in different regions of device
         memory and at 5.3 TB/s when they share one (tools/placement_probe.py, DESIGN.md "placement"); which region an
-        allocation lands in is the driver's choice.  So for vectors of PAIR_PROBE_MIN_BYTES or more, up to `tries`
-        candidates are allocated (the rejected ones are held until the choice is made, otherwise the driver hands
-        the same memory out again), each is timed against `ref` with the real pass run as a no-op, and the fastest is
-        kept.  Stops as soon as both regimes have been seen."""
+        allocation lands in is the driver's choice.  So candidates are allocated (the rejected ones are held until
+        the choice is made, otherwise the driver hands the same memory out again), each is timed against `ref` with
+        the real pass run as a no-op, and the fastest is kept.
+          * vectors >= 8 GiB: up to `tries` candidates, one after the other; stops as soon as both regimes have been
+            seen or a candidate is clearly in the good one;
+          * vectors of 1 - 8 GiB (C2: 4 GiB) are far less sensitive (6.38 TB/s right behind `ref`, 6.47 TB/s some tens of
+            GiB further on): three candidates, each pushed 32 GiB further by a spacer allocation."""
         nbytes = 4 * self.N
         if tries <= 1 or nbytes < self.PAIR_PROBE_MIN_BYTES:
             return self.new_vector()
+        big = nbytes >= self.PAIR_PROBE_BIG_BYTES
+        if not big:
+            tries = min(tries, 3)
         # the probe is the real pass: the factored XP sweep with alpha = beta = 0 over zeroed residual factors and a
         # zeroed candidate (x += 0 * 0 leaves ref as it is; the candidate stays zero)
         had_factors = self.ra is not None
@@ -131,13 +138,18 @@ class HipKernels:
         saved_scal = self.scal.clone()
         self.ra.zero_(), self.rb.zero_()
         self.scal[cabi.S_ALPHA], self.scal[cabi.S_BETA] = 0.0, 0.0
-        cands, rates = [], []
+        cands, rates, spacers = [], [], []
         for i in range(tries):
-            if i and torch.cuda.mem_get_info(self.device)[0] < nbytes + (2 << 30):
+            free = torch.cuda.mem_get_info(self.device)[0]
+            if i and free < nbytes + (2 << 30):
                 break
+            if i and not big:
+                if free < nbytes + (34 << 30):
+                    break
+                spacers.append(torch.empty(32 << 30, dtype=torch.uint8, device=self.device))
             v = self.new_vector().zero_()
             best = 1e30
-            for _ in range(2):
+            for _ in range(2 if big else 3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(self.device))
                 self.sweep(cabi.SWEEP_XP, ref, None, v, factored=True)
@@ -146,9 +158,9 @@ class HipKernels:
                 best = min(best, e0.elapsed_time(e1))
             cands.append(v)
             rates.append(4.0 * nbytes / best)
-            # done once both regimes have been seen, or when this candidate is clearly in the good one
+            # big vectors: done once both regimes have been seen, or when this candidate is clearly in the good one
             # (MI355X: ~6.3 TB/s vs ~5.3 TB/s, i.e. 0.79 vs 0.66 of the 8 TB/s peak; mixed placements fall in between)
-            if max(rates) >= 1.08 * min(rates) or rates[-1] * 1e3 >= 0.76 * self.HBM_PEAK_BYTES_PER_S:
+            if big and (max(rates) >= 1.08 * min(rates) or rates[-1] * 1e3 >= 0.76 * self.HBM_PEAK_BYTES_PER_S):
                 break
         self.scal.copy_(saved_scal)
         if saved is not None:
@@ -157,7 +169,7 @@ class HipKernels:
             self.ra = self.rb = self.zab = None
         keep = cands[max(range(len(cands)), key=rates.__getitem__)]
         self.pair_probe = [r / 1e6 for r in rates]            # GB/s of every candidate, for logs and tests
-        del cands, v
+        del cands, v, spacers
         torch.cuda.empty_cache()
         return keep
 

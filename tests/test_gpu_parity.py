@@ -456,7 +456,8 @@ def test_placement_probe_leaves_the_solve_unchanged(golden, monkeypatch):
     g = golden("cg_t8l4z4_32_r4")
     f = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV, placement_tries=3)
     x0 = f.x.clone()
-    f.start()
+    assert f._placement_tries(10) == 1 and f._placement_tries(None) == 1 and f._placement_tries(1000) == 3
+    f.start(planned_iterations=1000)
     assert torch.equal(f.x, x0) and 1 <= len(f.k.pair_probe) <= 3
     f.iterate(20)
     f.finish()
