@@ -31,6 +31,7 @@ NSCAL = 32
 NPART = 4
 EW_MAXBLOCKS = 2048
 MAX_SLICES = 16
+NOALLOC_MAX_PS = 65536
 SWEEP_PROJECT, SWEEP_XP, SWEEP_P, SWEEP_PINIT = range(4)
 
 _P = C.c_void_p
@@ -54,6 +55,7 @@ SIGNATURES = {
     "dfx_sweep_chunks": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P],
     "dfx_sweep_factored": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P],
     "dfx_resid_update": [_G, _P, _P, _P, _P, _f, _f, _f, _P, _i32, _P, _P, _P, _P],
+    "dfx_resid_update_noalloc": [_G, _P, _P, _P, _P, _f, _f, _f, _P, _i32, _P, _P],
     "dfx_sqnorm": [_P, _i64, _P, _i32, _P, _P],
     "dfx_sqdiff": [_P, _P, _P, _i64, _i64, _d, _P, _i32, _P, _P],
     "dfx_cg_alpha": [_P, _d, _d, _d, _P],

@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/dfx.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1230,6 +1232,43 @@ int launch_bcast_fast(const BcastArgs &a, const dfx_plan *pl, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Scratch of dfx_resid_update_noalloc: the zab workspace (DFX_NOALLOC_MAX_PS doubles) followed by the rows of
+// per-workgroup partials (DFX_EW_MAXBLOCKS * DFX_NPART doubles), 576 KiB, held by every GPU the library runs on until
+// the process ends.  In host code the array's NAME is a host-side stand-in, not a device address: host code only
+// ever uses the per-device pointer hipGetSymbolAddress returned (noalloc_scratch()), never the name.
+// ------------------------------------------------------------------------------------------
+__device__ __align__(256) double g_noalloc_scratch[DFX_NOALLOC_MAX_PS + DFX_EW_MAXBLOCKS * DFX_NPART];
+
+constexpr int kMaxDevices = 64;
+std::atomic<double *> g_noalloc_ptr[kMaxDevices];   // device address of g_noalloc_scratch on each GPU (each has its own)
+
+// The current device's copy of the scratch array; `stream` (if not the NULL stream) must belong to that device.
+int noalloc_scratch(hipStream_t st, double **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hipfail(e, "dfx_resid_update_noalloc: hipGetDevice");
+    if (dev < 0 || dev >= kMaxDevices) return fail(DFX_EINVAL, "dfx_resid_update_noalloc: device ordinal out of range");
+    if (st) {
+        int sdev = -1;
+        e = hipStreamGetDevice(st, &sdev);
+        if (e != hipSuccess) return hipfail(e, "dfx_resid_update_noalloc: hipStreamGetDevice");
+        if (sdev != dev)
+            return fail(DFX_EINVAL, "dfx_resid_update_noalloc: the stream's device is not the current device");
+    }
+    double *p = g_noalloc_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {   // once per device, with that device current
+        void *sym = nullptr;
+        e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_noalloc_scratch));
+        if (e != hipSuccess) return hipfail(e, "dfx_resid_update_noalloc: hipGetSymbolAddress");
+        if (!sym) return fail(DFX_EINVAL, "dfx_resid_update_noalloc: hipGetSymbolAddress returned NULL");
+        p = static_cast<double *>(sym);
+        g_noalloc_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return 0;
+}
+
 int fold(const double *parts, int n_rows, int nvals, double *dst, double scale, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, st, parts, n_rows, nvals, dst, scale);
     DFX_LAUNCH_CHECK("fold");
@@ -1426,14 +1465,9 @@ int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, floa
                       stream);
 }
 
-int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
-                     float coef_host, const double *coef_dev, int32_t accumulate, double *zab, double *scal,
-                     double *part, void *stream) {
-    Geo q;
-    if (int rc = make_geo(g, &q)) return rc;
-    if (!ra || !rb || !A || !B || !zab || !scal || !part) return fail(DFX_EINVAL, "dfx_resid_update: NULL buffer");
-    hipStream_t st = (hipStream_t)stream;
-    if (q.Ps > 0x7fffffffLL) return fail(DFX_EINVAL, "dfx_resid_update: plane too large");
+static int resid_update_impl(const Geo &q, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
+                             float coef_host, const double *coef_dev, int32_t accumulate, double *zab, double *scal,
+                             double *part, hipStream_t st) {
     const int groups = (int)((q.Ps + 15) / 16);
     const int nba = groups < DFX_EW_MAXBLOCKS / 2 ? groups : DFX_EW_MAXBLOCKS / 2;
     const int nbb = q.M < DFX_EW_MAXBLOCKS / 2 ? q.M : DFX_EW_MAXBLOCKS / 2;
@@ -1447,6 +1481,35 @@ int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, co
                        (double)q.nZ * q.r * q.r, scal);
     DFX_LAUNCH_CHECK("dfx_resid_update(rr)");
     return 0;
+}
+
+int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
+                     float coef_host, const double *coef_dev, int32_t accumulate, double *zab, double *scal,
+                     double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (!ra || !rb || !A || !B || !zab || !scal || !part) return fail(DFX_EINVAL, "dfx_resid_update: NULL buffer");
+    if (q.Ps > 0x7fffffffLL) return fail(DFX_EINVAL, "dfx_resid_update: plane too large");
+    return resid_update_impl(q, ra, rb, A, B, sa, sb, coef_host, coef_dev, accumulate, zab, scal, part,
+                             (hipStream_t)stream);
+}
+
+int dfx_resid_update_noalloc(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa,
+                             float sb, float coef_host, const double *coef_dev, int32_t accumulate, double *scal,
+                             void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (q.Ps > DFX_NOALLOC_MAX_PS)
+        return fail(DFX_EINVAL, "dfx_resid_update_noalloc: (X/r)*(Y/r) exceeds DFX_NOALLOC_MAX_PS (65536); use "
+                                "dfx_resid_update with a caller-provided workspace");
+    if (!ra || !rb || !A || !B || !scal) return fail(DFX_EINVAL, "dfx_resid_update_noalloc: NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    double *scratch = nullptr;   // this GPU's copy of g_noalloc_scratch (never the array's name)
+    if (int rc = noalloc_scratch(st, &scratch)) return rc;
+    // every element the kernels read is written earlier in this same call (zab[0, Ps) by k_resid_az, each partial row
+    // by its workgroup), so nothing needs clearing between calls; calls overlapping on one GPU would race on it
+    return resid_update_impl(q, ra, rb, A, B, sa, sb, coef_host, coef_dev, accumulate, scratch, scal,
+                             scratch + DFX_NOALLOC_MAX_PS, st);
 }
 
 int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in, const float *A,

@@ -286,6 +286,20 @@ class HipKernels:
                                self._stream()), "dfx_resid_update")
 
     @_on_device
+    def resid_update_noalloc(self, A, B, sa: float, sb: float, coef_host: float, coef_slot: int | None,
+                             accumulate: bool) -> None:
+        """resid_update through the entry point that takes no workspace (include/dfx.h: for callers that cannot
+        allocate; the scratch is a static device array inside libdfx.so).  Same kernels, same results."""
+        self._chk(A, B)
+        assert self.ra is not None and A.numel() == self.S and B.numel() == self.M * self.Xs * self.Ys
+        g, _ = self._g()
+        cabi.check(self.lib.dfx_resid_update_noalloc(g, cabi.ptr(self.ra), cabi.ptr(self.rb), cabi.ptr(A), cabi.ptr(B),
+                                                     sa, sb, coef_host,
+                                                     None if coef_slot is None else self.slot_ptr(coef_slot),
+                                                     int(accumulate), cabi.ptr(self.scal), self._stream()),
+                   "dfx_resid_update_noalloc")
+
+    @_on_device
     def axpy(self, y, x, coef_host: float, coef_slot: int | None) -> None:
         """y += coef * x ; XXNEW = ||y||^2."""
         self._chk(y, x)

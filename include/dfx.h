@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 112
+#define DFX_VERSION 113
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -77,6 +77,7 @@ enum {
 #define DFX_NPART 4          /* doubles per workgroup row of `part` */
 #define DFX_EW_MAXBLOCKS 2048 /* grid cap of the element-wise kernels */
 #define DFX_MAX_SLICES 16     /* most launches one sweep may be cut into (dfx_sweep_chunks) */
+#define DFX_NOALLOC_MAX_PS 65536 /* largest (X/r)*(Y/r) dfx_resid_update_noalloc accepts (its static scratch) */
 
 /* sweep modes */
 enum {
@@ -130,6 +131,17 @@ int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, co
 int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *ra,
                        const float *rb, float *p, double *scal, float *u_part, float *v_part, double *part,
                        int32_t c_lo, int32_t c_hi, int32_t slice, int32_t last, void *stream);
+
+/* dfx_resid_update without the `zab` and `part` workspace arguments.  It has NO counterpart in the reference: it exists
+ * for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc) and therefore cannot bring a workspace.  Same kernels, same results bit for bit; the scratch
+ * (zab + the per-workgroup partials, 576 KiB) is a static __device__ array inside the library, one copy per GPU,
+ * held until the process ends.  Limits: (X/r)*(Y/r) <= DFX_NOALLOC_MAX_PS, else DFX_EINVAL; the device of `stream`
+ * must be the current device; every call on one GPU shares that GPU's scratch, so calls that overlap on one GPU
+ * (two streams) race - serialise them.  Calls no hipMalloc / hipFree, and does not synchronise. */
+int dfx_resid_update_noalloc(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa,
+                             float sb, float coef_host, const double *coef_dev, int32_t accumulate, double *scal,
+                             void *stream);
 
 /* out = (in ? in : 0) + coef * mask * (sa * A[z,x,y] + sb * B[t,l,x/r,y/r]),
  * coef = coef_host * (coef_dev ? *coef_dev : 1); mask (nZ,X,Y) optional (NULL = ones).

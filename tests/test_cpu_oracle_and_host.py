@@ -114,7 +114,8 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"libdfx.so does not export {n}"
-    assert cabi.lib().dfx_version() == 112
+    hdr = open(os.path.join(ROOT, "include", "dfx.h")).read()
+    assert cabi.lib().dfx_version() == int(re.search(r"#define DFX_VERSION\s+(\d+)", hdr).group(1))
 
 
 def test_header_constants_match_python_mirror():
