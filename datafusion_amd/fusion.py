@@ -200,11 +200,24 @@ class Fusion:
         self.comm.sum_(k.scal[cabi.S_LOSS1:cabi.S_LOSS1 + 1])
         return k.scal[cabi.S_LOSS1].float(), k.scal[cabi.S_LOSS2].float()
 
+    def _save_solver_state(self):
+        """Hook for solvers whose loop keeps live state in k.u / k.v / scal (FusionCG): called before a projection of
+        x made from OUTSIDE the loop (loss(), marginals()); returns what _restore_solver_state needs, or None."""
+        return None
+
+    def _restore_solver_state(self, saved) -> None:
+        pass
+
     def loss(self):
-        """fusion.py:211-242 -> (spatial_loss, spectro_temporal_loss) as 0-dim device tensors."""
+        """fusion.py:211-242 -> (spatial_loss, spectro_temporal_loss) as 0-dim device tensors.  Safe to call between
+        two FusionCG.iterate() calls: the solver's projections and scalars are saved and put back."""
+        saved = self._save_solver_state()
         x = self.x.detach() if isinstance(self.x, torch.Tensor) else self.x
         self._project(x)
-        return self._losses_from_uv()
+        out = self._losses_from_uv()
+        out = (out[0].clone(), out[1].clone())
+        self._restore_solver_state(saved)
+        return out
 
     def marginals(self, which: str = "tl") -> torch.Tensor:
         """Device-side reductions of the fused volume (what the notebooks compute with numpy after a
@@ -213,10 +226,13 @@ class Fusion:
           "t"  -> x.sum(axis=0)       (l, z, x, y)
           "l"  -> x.sum(axis=1)       (t, z, x, y)
           "zxy"-> R(D(x))             (t, l, x/r, y/r), summed over shards  [= v(x)]"""
-        x = self.x.detach()
         if which in ("tl", "zxy"):
-            self._project(x)
-            return (self.k.u if which == "tl" else self.k.v).clone()
+            saved = self._save_solver_state()
+            self._project(self.x.detach())
+            out = (self.k.u if which == "tl" else self.k.v).clone()
+            self._restore_solver_state(saved)
+            return out
+        x = self.x.detach()
         if which in ("t", "l"):
             return self.k.sum_axis(x, 0 if which == "t" else 1)
         raise ValueError("which must be one of 'tl', 't', 'l', 'zxy'")
@@ -266,6 +282,23 @@ class FusionCG(Fusion):
         t_ar = 4.0 * self.n_times * self.n_lambdas * self.spc.shape[-2] * self.spc.shape[-1] / 70e9 + 30e-6
         cost = {k: t_ar * 2.0 / (k * (k + 1)) + 50e-6 * (k - 1) for k in range(1, cabi.MAX_SLICES + 1)}
         return min(cost, key=cost.get)
+
+    def _save_solver_state(self):
+        """loss() / marginals() project x into k.u, k.v and overwrite UU, PP, XX, XP - which, between two iterate()
+        calls, hold u(p), v(p) and the norms the next iteration's alpha, residual update and tolerance are computed
+        from.  Apply an x update still owed (loop left by tolerance), then save them."""
+        if self._p is None:
+            return None
+        if self._pending_x:
+            self.k.axpy(self.x, self._p, 1.0, cabi.S_ALPHA)
+            self._pending_x = False
+        k = self.k
+        return k.u.clone(), k.v.clone(), k.scal[cabi.S_UU:cabi.S_XP + 1].clone()
+
+    def _restore_solver_state(self, saved) -> None:
+        if saved is not None:
+            k = self.k
+            k.u.copy_(saved[0]), k.v.copy_(saved[1]), k.scal[cabi.S_UU:cabi.S_XP + 1].copy_(saved[2])
 
     def _sweep(self, mode) -> None:
         """One pass over x, r, p.  When the volume is z-sharded the pass is cut into `comm_slices` launches along
@@ -359,6 +392,10 @@ class FusionCG(Fusion):
         c1, c2 = self._coefs()
         x, rv, pv = self.x, self._r, self._p
         deferred = self.defer_x
+        if history is not None and deferred:
+            # a per-iteration loss needs the current x, and the two schedules cannot alternate (SWEEP_P leaves no
+            # ||x||^2, <x,p> for a deferred tolerance): construct with defer_x=False (verbose=True does)
+            raise ValueError("iterate(history=...) needs the textbook schedule: construct with defer_x=False")
         for i in range(int(n_iterations)):
             if self._stopped:
                 break
@@ -375,14 +412,14 @@ class FusionCG(Fusion):
                 k.bcast(rv, rv, k.u, k.v, None, c1, c2, -1.0, cabi.S_ALPHA)
             c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
             k.cg_beta(eps, deferred)                                            # rsnew, tol, beta
-            if self.tol is not None or self.verbose:
+            if self.tol is not None or self.verbose or history is not None:
                 s = k.scal.cpu()                                                # one sync, as fusion.py:448
                 assert bool(s[cabi.S_NONFINITE] == 0), "Conjugate gradient diverged"
                 if self.tol is not None and float(s[cabi.S_TOL]) < self.tol:    # fusion.py:451-453
                     self._stopped = True
                     break
             if history is not None:                                             # fusion.py:458-478
-                l1, l2 = self.loss()                                            # x is current: defer_x is off
+                l1, l2 = self.loss()                                            # x is current: textbook schedule
                 history[i] = [float(l1), float(l2), float(l1) + float(l2), float(s[cabi.S_RSNEW])]
             self._sweep(cabi.SWEEP_XP if deferred else cabi.SWEEP_P)            # fusion.py:445,455
             self._pending_x = False

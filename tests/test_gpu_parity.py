@@ -501,3 +501,78 @@ def test_inputs_as_tensors_of_other_dtypes_and_devices(golden):
     xt, st, ct = FusionCG(g["spc"], g["cmos"], weights=W(g), init_type="baseline", tol=None, device=DEV)(
         5, return_numpy=False)
     assert isinstance(xt, torch.Tensor) and xt.device.type == "cuda" and np.array_equal(xt.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("residual,defer", [("factored", True), ("explicit", True), ("factored", False)])
+def test_loss_and_marginals_between_iterate_calls_leave_the_solve_unchanged(residual, defer):
+    """start() / iterate(n) / finish() is a public way to interleave iterations with other work:
+    loss() and marginals() project x through the solver's own u, v and scalar slots, so they must put the solver's
+    live state back - iterate(3); loss(); marginals(); iterate(3) is bit-identical to iterate(6)."""
+    from datafusion_amd import FusionCG
+    w = {"spatial": 0.4, "spectro_temporal": 0.6}
+    spc, cmos = O.cells_like_inputs(10, 6, 11, 64, 4, seed=17)
+    kw = dict(weights=w, init_type="baseline", tol=None, device=DEV, residual=residual, defer_x=defer)
+    a = FusionCG(spc, cmos, **kw)
+    a.start()
+    a.iterate(6)
+    a.finish()
+    b = FusionCG(spc, cmos, **kw)
+    b.start()
+    b.iterate(3)
+    l1, l2 = b.loss()
+    m = b.marginals("zxy")
+    b.marginals("tl"), b.marginals("t")
+    b.iterate(3)
+    b.finish()
+    assert torch.equal(a.x, b.x)
+    assert torch.equal(a.k.scal[:12], b.k.scal[:12])
+    # and the loss reported in between is the loss of the iterate after three iterations
+    c = FusionCG(spc, cmos, **kw)
+    xc, _, _ = c(3, return_numpy=False)
+    m1, m2 = c.loss()
+    assert float(l1) == float(m1) and float(l2) == float(m2)
+    assert torch.equal(m, c.marginals("zxy"))
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
+    O.cg(pb, 3, with_loss=False)
+    o1, o2 = O.loss(pb)
+    assert np.allclose([float(l1), float(l2)], [float(o1), float(o2)], rtol=1e-3)
+
+
+def test_loss_after_a_tolerance_stop_sees_the_last_update():
+    """A loop left through the tolerance test owes x its last alpha * p until finish(); loss() called before finish()
+    applies it first (and finish() then has nothing left to add)."""
+    from datafusion_amd import FusionCG
+    w = {"spatial": 0.5, "spectro_temporal": 0.5}
+    spc, cmos = O.synthetic_inputs(8, 4, 4, 32, 4, seed=6)
+    f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=3e-3, device=DEV)
+    f.start()
+    f.iterate(50)
+    assert f._stopped and f._pending_x
+    l1, l2 = f.loss()
+    assert not f._pending_x
+    f.finish()
+    g = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=3e-3, device=DEV)
+    xg, _, _ = g(50, return_numpy=False)
+    assert g.curr_iter == f.curr_iter and torch.equal(f.x, xg)
+    m1, m2 = g.loss()
+    assert float(l1) == float(m1) and float(l2) == float(m2)
+
+
+def test_iterate_with_a_history_array_needs_the_textbook_schedule():
+    from datafusion_amd import FusionCG
+    w = {"spatial": 0.5, "spectro_temporal": 0.5}
+    spc, cmos = O.synthetic_inputs(4, 3, 3, 16, 4, seed=7)
+    f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV)
+    f.start()
+    with pytest.raises(ValueError, match="defer_x=False"):
+        f.iterate(2, history=np.zeros((2, 4)))
+    f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV, defer_x=False)
+    h = np.zeros((4, 4))
+    f.start()
+    f.iterate(4, history=h)            # tol=None, verbose=False: used to raise NameError
+    f.finish()
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
+    O.cg(pb, 4)
+    ref = np.array([[t["spatial_loss"], t["spectro_temporal_loss"], t["spatial_loss"] + t["spectro_temporal_loss"],
+                     t["rsnew"]] for t in pb.trace])
+    assert np.allclose(h, ref, rtol=1e-3, atol=1e-13)
