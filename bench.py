@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+PMC_RECORD = "r02_pmc_traffic.json"   # written by tools/profile_all.sh; carries the sha256 of the kernel source it was taken on
 
 WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "c2": (256, 16, 16, 128, 4),
@@ -46,28 +47,55 @@ def synthetic(n_t, n_l, n_z, xy, r, seed=0):
     return spc, cmos
 
 
-def cpu_baseline(n_l, n_z, xy, r, full_n, budget_s=15.0):
-    """The oracle (eager-faithful torch-CPU port of fusion.py:423-456, per-iteration loss included)
-    timed on this host on a bounded sample: same geometry, fewer time bins; scaled 1/N to the
-    full workload.  Reported, never the target."""
+def _host_facts():
+    model, avail = "unknown", 0
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return model, avail
+
+
+def cpu_baseline(n_t, n_l, n_z, xy, r, iters=2):
+    """The oracle (eager-faithful torch-CPU port of fusion.py:423-456, per-iteration loss included) timed on this
+    host on the FULL workload when host memory allows (the eager loop holds ~12 N-sized fp32 tensors: ~52 GB for C2),
+    otherwise on the same geometry with fewer time bins, scaled by N and labelled so.  One call of `iters` iterations:
+    b and r0 = b - A(x0) (fusion.py:428-437) are paid once and reported separately, as a reference call pays them.
+    Reported, never the target."""
     from oracle import fusion_oracle as O
-    n_t = 16
+    model, avail = _host_facts()
+    full_n = n_t * n_l * n_z * xy * xy
+    need = 12 * 4 * full_n
+    t_use = n_t
+    if avail and need * 1.3 > avail:                       # bounded sample: same planes, fewer time bins
+        t_use = max(2, int(n_t * avail / (need * 1.6)))
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
+    spc = spc[:t_use].contiguous()
     w = {"spatial": 0.5, "spectro_temporal": 0.5}
+    t0 = time.perf_counter()
     pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
-    O.cg(pb, 1)  # warm
-    iters, t0 = 0, time.perf_counter()
-    while True:
-        O.cg(pb, 2)          # each call pays b and r0 once, like a reference call would
-        iters += 2
-        dt = time.perf_counter() - t0
-        if dt > budget_s or iters >= 200:
-            break
-    n_sample = n_t * n_l * n_z * xy * xy
-    its = iters / dt
+    t_prep = time.perf_counter() - t0
+    tm = {}
+    O.cg(pb, iters, timings=tm)
+    n_sample = t_use * n_l * n_z * xy * xy
+    per_iter = sum(tm["iter_s"]) / len(tm["iter_s"])
+    its = 1.0 / per_iter
+    full = t_use == n_t
+    what = (f"oracle/fusion_oracle.cg on the full workload t{n_t}xl{n_l}xz{n_z}x{xy}x{xy} (N={full_n})" if full else
+            f"oracle/fusion_oracle.cg on t{t_use}xl{n_l}xz{n_z}x{xy}x{xy} (N={n_sample}: host has {avail / 2**30:.0f} GiB "
+            f"available, the full workload needs ~{need * 1.3 / 2**30:.0f}), it/s scaled by N_sample/N_full")
     return {"value": its * n_sample / full_n, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/fusion_oracle.cg on t{n_t}xl{n_l}xz{n_z}x{xy}x{xy} (N={n_sample}), {iters} iterations "
-                      f"in {dt:.1f}s incl. b/r0 every 2 iterations = {its:.3f} it/s, scaled by N_sample/N_full"}
+            "cpu_model": model, "extrapolated": not full,
+            "sample": f"{what}; one call of {iters} iterations: {', '.join(f'{t:.2f}' for t in tm['iter_s'])} s each; b and r0 "
+                      f"paid once: {tm['setup_s']:.2f} s; constructor (baseline init + normalisation): {t_prep:.2f} s "
+                      "(both excluded from it/s, like the GPU figure)",
+            "iter_s": tm["iter_s"], "setup_b_r0_s": tm["setup_s"], "constructor_s": t_prep}
 
 
 def bench_adam(a, world, rank, dev, group, use_dist):
@@ -215,18 +243,31 @@ def main():
         ach = res["sweep_bytes"] / (res["sweep_ms"] * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": f"k_sweep_fast<{'P' if a.no_defer else 'XP'},{res['zc']},r{r},{residual}>",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                "traffic": traffic, "bytes_per_launch": res["sweep_bytes"], "avg_launch_ms": res["sweep_ms"]}
+                "traffic": traffic[0], "traffic_source": traffic[1],
+                "bytes_per_launch": res["sweep_bytes"], "avg_launch_ms": res["sweep_ms"],
+                "basis": "bytes the kernel must move (x, p read + written; + r read when explicit) / HIP-event time of "
+                         "its launches inside the timed region"}
 
     def pmc_traffic(residual, zc):
-        # HBM bytes per launch from the committed PMC passes of this same command (profiles/): counters cannot be
-        # collected from inside the process being profiled, so the figure is read back, for the workload it was taken on
+        """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (counters cannot
+        be collected from inside the process being profiled: tools/profile_all.sh runs this same command under
+        rocprofv3 --pmc).  Returned only when that record was taken on the kernel source this run's library was built
+        from (sha256 of dfx_kernels.hip) and on this workload; otherwise None.  -> (bytes or None, provenance)."""
+        import hashlib
+        path = os.path.join(ROOT, "profiles", PMC_RECORD)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pmc["workload"] == a.workload and world == 1 and not a.no_defer:
-                return pmc["kernels"][f"k_sweep_fast<XP,{zc},r{r},{residual}>"]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
-        return None
+            pmc = json.load(open(path))
+            src = hashlib.sha256(open(os.path.join(ROOT, "datafusion_amd", "csrc", "dfx_kernels.hip"), "rb").read()).hexdigest()
+            if pmc.get("kernel_source_sha256") != src:
+                return None, f"none: profiles/{PMC_RECORD} was taken on another build of dfx_kernels.hip"
+            if pmc["workload"] != a.workload or world != 1 or a.no_defer:
+                return None, f"none: profiles/{PMC_RECORD} holds workload {pmc['workload']}, 1 GPU, deferred x update"
+            rec = pmc["kernels"][f"k_sweep_fast<XP,{zc},r{r},{residual}>"]
+            return rec["traffic_bytes"], (f"replayed from profiles/{PMC_RECORD} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                          f"of this command on this kernel source, sha256 {src[:12]}; FETCH_SIZE doubled per "
+                                          "MI355X_MICROARCH.md): not a measurement of this run")
+        except (OSError, KeyError, ValueError) as e:
+            return None, f"none: {type(e).__name__} reading profiles/{PMC_RECORD}"
 
     main_res = run(a.residual)
     other = "explicit" if a.residual == "factored" else "factored"
@@ -273,7 +314,7 @@ def main():
             "roofline": roofline(o, other, pmc_traffic(other, o["zc"]))}
     if rank == 0:
         if not a.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n_l, n_z, xy, r, n_total)
+            out["cpu_baseline"] = cpu_baseline(n_t, n_l, n_z, xy, r)
         emit(out)
     if use_dist:
         dist.barrier()

@@ -216,15 +216,27 @@ def rhs(pb: Problem) -> torch.Tensor:
 
 
 @torch.no_grad()
-def cg(pb: Problem, max_iterations: int, eps: float = 1e-10, with_loss: bool = True) -> torch.Tensor:
+def cg(pb: Problem, max_iterations: int, eps: float = 1e-10, with_loss: bool = True,
+       timings: dict | None = None) -> torch.Tensor:
     """The loop of fusion.py:435-456, same op order, same eps placement.  Appends one dict per
     iteration to pb.trace.  `with_loss=False` skips the per-iteration loss() (fusion.py:458),
-    which does not influence x."""
+    which does not influence x.  `timings` (bench.py's cpu_baseline leg): filled with "setup_s" (b, r0, rsold:
+    fusion.py:428-437, paid once per call) and "iter_s" (wall time of each loop pass)."""
+    import time
+    t_start = time.perf_counter()
     b = rhs(pb)
     r = b - normal_op(pb, pb.x)                                # fusion.py:435
     p = r
     rsold = torch.dot(r.flatten(), r.flatten())
+    if timings is not None:
+        timings["setup_s"] = time.perf_counter() - t_start
+        timings["iter_s"] = []
+    t_iter = time.perf_counter()
     for _ in range(int(max_iterations)):
+        if timings is not None and pb.trace and len(timings["iter_s"]) < len(pb.trace):
+            now = time.perf_counter()
+            timings["iter_s"].append(now - t_iter)
+            t_iter = now
         pb.curr_iter += 1
         prev_x = pb.x.clone() if pb.tol is not None else None  # fusion.py:441
         ap = normal_op(pb, p)
@@ -245,6 +257,8 @@ def cg(pb: Problem, max_iterations: int, eps: float = 1e-10, with_loss: bool = T
             l1, l2 = loss(pb)
             rec["spatial_loss"], rec["spectro_temporal_loss"] = float(l1), float(l2)
         pb.trace.append(rec)
+    if timings is not None and len(timings["iter_s"]) < len(pb.trace):
+        timings["iter_s"].append(time.perf_counter() - t_iter)
     return pb.x
 
 
