@@ -107,7 +107,8 @@ def bench_adam(a, world, rank, dev, group, use_dist):
                    device=dev, group=group, fused=(a.method == "adam"), moment1=a.moment1)
     n_local = f.k.N
     f(lr=1e-8, max_iterations=a.warmup, return_numpy=False)
-    f.k.timing = {}
+    main_kernel = "adamf" if a.moment1 == "factored" else "adam"
+    f.k.timing, f.k.timing_names = {}, ({main_kernel} if a.method == "adam" else set())
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -117,7 +118,14 @@ def bench_adam(a, world, rank, dev, group, use_dist):
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in f.k.timing.items()}
+    timing = f.k.timing
+    f.k.timing, f.k.timing_names = {}, None          # breakdown of the other launches: a second, untimed run
+    f(lr=1e-8, max_iterations=a.steps, return_numpy=False)
+    torch.cuda.synchronize()
+    for name, evs in f.k.timing.items():
+        timing.setdefault(name, evs)
+    f.k.timing = None
+    kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in timing.items()}
     its = a.steps / dt
     out = {"metric": "FusionAdam iters/sec (secondary; BASELINE.json configs[4] shape class)", "value": its * world,
            "iters_per_s": its, "unit": "it/s",
@@ -207,15 +215,25 @@ def main():
         f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
                      mask_noise=False, total_energy=1, device=dev, seed=42, group=group, defer_x=not a.no_defer,
                      target_blocks=a.target_blocks, residual=residual, comm_slices=a.comm_slices if a.comm_slices == "auto" else int(a.comm_slices))
+        fact = residual == "factored"
+        sweep_name = ("sweep2" if a.no_defer else "sweep1") + ("f" if fact else "")
         f.start()
         f.iterate(a.warmup)
-        f.k.timing = {}
+        # the timed region: HIP events bracket the dominant kernel only (roofline.achieved comes from them) ...
+        f.k.timing, f.k.timing_names = {}, {sweep_name}
         fence()
         t0 = time.perf_counter()
         f.iterate(a.steps)
         fence()
         dt = time.perf_counter() - t0
-        timing, f.k.timing = f.k.timing, None
+        timing = f.k.timing
+        # ... the other entry points are timed in a second, untimed loop (kernel_ms is a breakdown, not the metric)
+        f.k.timing, f.k.timing_names = {}, None
+        f.iterate(a.steps)
+        torch.cuda.synchronize()
+        detail, f.k.timing = f.k.timing, None
+        for name, evs in detail.items():
+            timing.setdefault(name, evs)
         f.finish()  # raises if the residual ever went non-finite
         if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -224,8 +242,6 @@ def main():
         # per-iteration time of each entry point from the HIP events recorded on the launch stream inside the
         # timed region (a z-sharded sweep is cut into several launches: sum them)
         kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in timing.items()}
-        fact = residual == "factored"
-        sweep_name = ("sweep2" if a.no_defer else "sweep1") + ("f" if fact else "")
         # words the sweep must move: x, p read + written (deferred x update) or p read + written, plus
         # the read of r when it is an explicit 5-D vector
         sweep_words = (2 if a.no_defer else 4) + (0 if fact else 1)

@@ -26,13 +26,16 @@ class Plan(C.Structure):
 
 # slots of the device state `scal` (include/dfx.h)
 S_RSOLD, S_RSNEW, S_PAP, S_ALPHA, S_BETA, S_TOL, S_UU, S_PP, S_XX, S_XP, S_VV, S_RR, S_XXNEW, S_NONFINITE, \
-    S_ITER, S_SUM, S_SCALE, S_LOSS1, S_LOSS2, S_ADAM_DD, S_ADAM_XX, S_RA2, S_RB2, S_RAB = range(24)
+    S_ITER, S_SUM, S_SCALE, S_LOSS1, S_LOSS2, S_ADAM_DD, S_ADAM_XX, S_RA2, S_RB2, S_RAB, S_ALPHA_LAST = range(25)
 NSCAL = 32
 NPART = 4
 EW_MAXBLOCKS = 2048
 MAX_SLICES = 16
 NOALLOC_MAX_PS = 65536
 SWEEP_PROJECT, SWEEP_XP, SWEEP_P, SWEEP_PINIT = range(4)
+LAST_NO, LAST_FOLD, LAST_NOFOLD = range(3)
+POST_U, POST_V, POST_V_SUMMED, POST_FOLD_SWEEP, POST_FOLD_ADAM, POST_ALPHA = 1, 2, 4, 8, 16, 32
+ADAM_NONNEG, ADAM_NOFOLD = 1, 2
 
 _P = C.c_void_p
 _G = C.POINTER(Geom)
@@ -50,12 +53,15 @@ SIGNATURES = {
     "dfx_adam_step": [_G, _PL, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _i32, _i32, _P, _P, _P, _P, _P],
     "dfx_adam_step_factored": [_G, _PL, _P, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _i32, _i32, _P, _P, _P, _P, _P],
     "dfx_lerp": [_P, _P, _i64, _d, _P],
+    "dfx_adam_prep": [_P, _P, _P, _P, _P, _i64, _P, _P, _P, _i64, _P, _P, _i64, _d, _d, _d, _P, _P, _P],
     "dfx_reduce_u": [_G, _PL, _P, _P, _P, _P, _P],
     "dfx_reduce_v": [_G, _PL, _P, _P, _i64, _i64, _P],
     "dfx_sweep_chunks": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P],
     "dfx_sweep_factored": [_i32, _G, _PL, _P, _P, _P, _P, _P, _P, _P, _P, _i32, _i32, _i32, _i32, _P],
     "dfx_resid_update": [_G, _P, _P, _P, _P, _f, _f, _f, _P, _i32, _P, _P, _P, _P],
     "dfx_resid_update_noalloc": [_G, _P, _P, _P, _P, _f, _f, _f, _P, _i32, _P, _P],
+    "dfx_resid_cg_step": [_G, _P, _P, _P, _P, _d, _d, _d, _i32, _P, _P, _P, _P],
+    "dfx_post_sweep": [_G, _PL, _P, _P, _P, _P, _P, _P, _i32, _i32, _d, _d, _d, _P],
     "dfx_sqnorm": [_P, _i64, _P, _i32, _P, _P],
     "dfx_sqdiff": [_P, _P, _P, _i64, _i64, _d, _P, _i32, _P, _P],
     "dfx_cg_alpha": [_P, _d, _d, _d, _P],

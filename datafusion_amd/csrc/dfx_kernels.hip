@@ -34,10 +34,13 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define DFX_WAVES 4       // waves per workgroup of the fast kernels (each wave owns one wave tile)
 #endif
 #ifndef DFX_ADAM_ZB
-#define DFX_ADAM_ZB 16     // same for k_adam_fast: all zc planes at once measured best (4.5-4.6 ms at C2)
+#define DFX_ADAM_ZB 2     // same for k_adam_fast
 #endif
 #ifndef DFX_BCAST_INFLIGHT
 #define DFX_BCAST_INFLIGHT 8  // float4 loads a lane of k_bcast_fast keeps in flight (slabs per trip = this / zc)
+#endif
+#ifndef DFX_ADAM_FASTMATH
+#define DFX_ADAM_FASTMATH 1   // 1: v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sqrt and division sequences
 #endif
 #ifndef DFX_ZB
 #define DFX_ZB 2          // z planes whose loads are issued together, then updated and stored (finer read/write
@@ -497,8 +500,15 @@ template <bool M1F>
 __device__ __forceinline__ float adam_elem(float x, float g, float &m1, float &m2, const AdamArgs &a) {
     if (!M1F) m1 = m1 + a.omb1 * (g - m1);                // exp_avg.lerp_(grad, 1 - beta1); M1F: m1 is already new
     m2 = a.b2 * m2 + a.omb2 * (g * g);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+#if DFX_ADAM_FASTMATH
+    // the hardware square root and reciprocal are good to 1 ulp: the step changes by < 3e-7 of itself, far below one
+    // ulp of x for any step that does not swamp x; exp_avg_sq (the state carried on) is exact either way
+    const float denom = __builtin_amdgcn_sqrtf(m2) * a.inv_sqrt_bc2 + a.eps;
+    float xn = x - a.step_size * (m1 * __builtin_amdgcn_rcpf(denom));
+#else
     const float denom = __fsqrt_rn(m2) * a.inv_sqrt_bc2 + a.eps;
     float xn = x - a.step_size * __fdiv_rn(m1, denom);    // param.addcdiv_(exp_avg, denom, value=-step_size)
+#endif
     if (a.non_neg) xn = fmaxf(xn, 0.f);                   // fusion.py:344-346
     return xn;
 }
@@ -517,83 +527,61 @@ __device__ __forceinline__ f4 adam_elem4(f4 x, f4 g, f4 &m1, f4 &m2, const AdamA
     return (f4){x0, x1, x2, x3};
 }
 
-// One slab's worth of a lane's operands.  The kernel keeps two: the loads of slab m + gz are issued before the
-// arithmetic of slab m starts.  With the factored first moment the pass moves 4N words and the sqrt + division per
-// element (~1.2 ms of VALU time at C2) is no longer hidden behind memory time by a single resident wave per SIMD.
-template <int ZC>
-struct AdamSlab {
-    f4 x[ZC], e1[ZC], e2[ZC];
-    f4 b, mb;
-};
-
-template <int ZC, int R, bool M1F, int ZN>
-__device__ __forceinline__ void adam_load(const AdamArgs &a, AdamSlab<ZC> &s, const LaneMap<R> &L, int m,
-                                          long long off) {
-    const long long base = (long long)m * a.q.S + off;
-    s.b = L.bload(a.B + (long long)m * a.q.Ps);
-    s.mb = (f4){0.f, 0.f, 0.f, 0.f};
-    if (M1F) s.mb = L.bload(a.m1b + (long long)m * a.q.Ps);
-#pragma unroll
-    for (int k = 0; k < ZN; ++k) {
-        const long long i = base + (long long)k * a.q.P;
-        s.x[k] = ld4s(a.x + i);
-        if (!M1F) s.e1[k] = ld4s(a.m1 + i);
-        s.e2[k] = ld4s(a.m2 + i);
-    }
-}
-
-template <int ZC, int R, bool HAS_MASK, bool M1F, int ZN>
-__device__ __forceinline__ void adam_apply(const AdamArgs &a, AdamSlab<ZC> &s, const LaneMap<R> &L, int m,
-                                           long long off, const f4 (&av)[ZC], const f4 (&mk)[ZC],
-                                           const f4 (&m1av)[ZC], f4 (&uacc)[ZC], float *vbase, int lane, double &ddd,
-                                           double &dxx) {
-    const long long base = (long long)m * a.q.S + off;
-    f4 s4 = {0.f, 0.f, 0.f, 0.f};
-    float dd = 0.f, xx = 0.f;
-#pragma unroll
-    for (int k = 0; k < ZN; ++k) {
-        {
-            const long long i = base + (long long)k * a.q.P;
-            f4 g = av[k] + s.b;
-            if (HAS_MASK) g *= mk[k];
-            if (M1F) {
-                s.e1[k] = m1av[k] + s.mb;
-                if (HAS_MASK) s.e1[k] *= mk[k];
-            }
-            const f4 xn = adam_elem4<M1F>(s.x[k], g, s.e1[k], s.e2[k], a);
-            st4s(a.x + i, xn);
-            if (!M1F) st4s(a.m1 + i, s.e1[k]);
-            st4s(a.m2 + i, s.e2[k]);
-            const f4 d = xn - s.x[k];
-            dd += dot4(d, d);
-            xx += dot4(xn, xn);
-            uacc[k] += xn;
-            s4 += xn;
-        }
-    }
-    L.vstore(s4, vbase + (long long)m * a.q.Ps, lane);
-    ddd += (double)dd;
-    dxx += (double)xx;
-}
-
-// the slabs m0, m0 + gz, ... < m1e of one u_part chunk, ZN live planes, two register sets in ping-pong
+// The slabs m0, m0 + gz, ... < m1e of one u_part chunk, ZN live planes: the sweep's structure - DFX_ADAM_ZB planes
+// loaded, updated and stored at a time.  (Measured at C2, factored first moment, with the hardware sqrt / rcp: 2 planes
+// 2.70 ms, 3: 2.78, 4: 2.80, 8: 2.87, 1: 3.80; whole slabs in two register sets in ping-pong, the round-1 loop, 2.87;
+// with the IEEE sqrt / division sequences 2 planes take 2.85: both changes are needed.)
 template <int ZC, int R, bool HAS_MASK, bool M1F, int ZN>
 __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &L, int m0, int m1e, int gz,
-                                           long long off, const f4 (&av)[ZC], const f4 (&mk)[ZC],
-                                           const f4 (&m1av)[ZC], f4 (&uacc)[ZC], float *vbase, int lane, double &ddd,
-                                           double &dxx) {
-    AdamSlab<ZC> sa, sb;   // one being updated, the other in flight
-    int m = m0;
-    if (m < m1e) adam_load<ZC, R, M1F, ZN>(a, sa, L, m, off);
-    while (m < m1e) {
-        const int mb = m + gz, ma = mb + gz;
-        if (mb < m1e) adam_load<ZC, R, M1F, ZN>(a, sb, L, mb, off);
-        adam_apply<ZC, R, HAS_MASK, M1F, ZN>(a, sa, L, m, off, av, mk, m1av, uacc, vbase, lane, ddd, dxx);
-        if (mb < m1e) {
-            if (ma < m1e) adam_load<ZC, R, M1F, ZN>(a, sa, L, ma, off);
-            adam_apply<ZC, R, HAS_MASK, M1F, ZN>(a, sb, L, mb, off, av, mk, m1av, uacc, vbase, lane, ddd, dxx);
+                                              long long off, const f4 (&av)[ZC], const f4 (&mk)[ZC],
+                                              const f4 (&m1av)[ZC], f4 (&uacc)[ZC], float *vbase, int lane,
+                                              double &ddd, double &dxx) {
+    constexpr int ZB = ZC < DFX_ADAM_ZB ? ZC : DFX_ADAM_ZB;
+    for (int m = m0; m < m1e; m += gz) {
+        const long long base = (long long)m * a.q.S + off;
+        const f4 b4 = L.bload(a.B + (long long)m * a.q.Ps);
+        f4 mb4 = {0.f, 0.f, 0.f, 0.f};
+        if (M1F) mb4 = L.bload(a.m1b + (long long)m * a.q.Ps);
+        f4 s4 = {0.f, 0.f, 0.f, 0.f};
+        float dd = 0.f, xx = 0.f;
+#pragma unroll
+        for (int g = 0; g < ZC; g += ZB) {
+            f4 xv[ZB], e1[ZB], e2[ZB];
+#pragma unroll
+            for (int j = 0; j < ZB; ++j) {
+                if (g + j < ZN) {
+                    const long long i = base + (long long)(g + j) * a.q.P;
+                    xv[j] = ld4s(a.x + i);
+                    if (!M1F) e1[j] = ld4s(a.m1 + i);
+                    e2[j] = ld4s(a.m2 + i);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ZB; ++j) {
+                if (g + j < ZN) {
+                    const int k = g + j;
+                    const long long i = base + (long long)k * a.q.P;
+                    f4 gr = av[k] + b4;
+                    if (HAS_MASK) gr *= mk[k];
+                    if (M1F) {
+                        e1[j] = m1av[k] + mb4;
+                        if (HAS_MASK) e1[j] *= mk[k];
+                    }
+                    const f4 xn = adam_elem4<M1F>(xv[j], gr, e1[j], e2[j], a);
+                    st4s(a.x + i, xn);
+                    if (!M1F) st4s(a.m1 + i, e1[j]);
+                    st4s(a.m2 + i, e2[j]);
+                    const f4 d = xn - xv[j];
+                    dd += dot4(d, d);
+                    xx += dot4(xn, xn);
+                    uacc[k] += xn;
+                    s4 += xn;
+                }
+            }
         }
-        m = ma;
+        L.vstore(s4, vbase + (long long)m * a.q.Ps, lane);
+        ddd += (double)dd;
+        dxx += (double)xx;
     }
 }
 
@@ -842,6 +830,217 @@ __global__ __launch_bounds__(256) void k_fold(const double *parts, int n_rows, i
     }
 }
 
+// sum over rows [0, n_rows) of column k of a DFX_NPART-wide table, by the whole workgroup (256 threads), fixed order
+__device__ __forceinline__ double fold_col(const double *parts, int n_rows, int k, double *sh) {
+    double s = 0;
+    for (int b = threadIdx.x; b < n_rows; b += 256) s += parts[(long long)b * DFX_NPART + k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ void cg_alpha_body(double *s, double c1, double c2, double eps) {
+    // float arithmetic where the reference has 0-dim fp32 tensors (fusion.py:444)
+    const float pap = (float)(c1 * s[DFX_S_UU] + c2 * s[DFX_S_VV]);
+    s[DFX_S_PAP] = (double)pap;
+    const float alpha = (float)s[DFX_S_RSOLD] / (pap + (float)eps);
+    s[DFX_S_ALPHA] = (double)alpha;
+}
+
+__device__ __forceinline__ void cg_beta_body(double *s, double eps, int deferred) {
+    const double rsnew = s[DFX_S_RR];
+    s[DFX_S_RSNEW] = rsnew;
+    if (!isfinite(rsnew)) s[DFX_S_NONFINITE] += 1.0;
+    const double al = s[DFX_S_ALPHA];
+    const double pp = s[DFX_S_PP];
+    const double xx_new = deferred ? (s[DFX_S_XX] + 2.0 * al * s[DFX_S_XP] + al * al * pp) : s[DFX_S_XXNEW];
+    s[DFX_S_TOL] = fabs(al) * sqrt(pp) / sqrt(xx_new);
+    const float beta = (float)rsnew / ((float)s[DFX_S_RSOLD] + (float)eps);
+    s[DFX_S_BETA] = (double)beta;
+    s[DFX_S_RSOLD] = rsnew;
+    s[DFX_S_ALPHA_LAST] = al;      // the alpha of the iteration just closed (ALPHA itself is renewed after the sweep)
+    s[DFX_S_ITER] += 1.0;
+}
+
+// Everything that follows a sweep (or a fused Adam step), in TWO launches:
+//  k_post_sweep, many workgroups:
+//   workgroups [0, nbu):        u = sum_rows u_part ; partial sum u^2                      (DFX_POST_U)
+//   workgroups [nbu, nbu+nbv):  v = sum_zchunks v_part (if n_zchunks > 1) ; partial sum v^2  (DFX_POST_V)
+//  k_post_fold, one workgroup (fixed order: deterministic):
+//   UU, VV ; the sweep's / Adam step's own partial rows -> PP, XX, XP or ADAM_DD, ADAM_XX (DFX_POST_FOLD_*) ;
+//   alpha of the next iteration (DFX_POST_ALPHA, fusion.py:444).
+// (Folding inside k_post_sweep by "the last workgroup to finish" was measured and dropped: the device-scope release
+// every workgroup needs before taking its ticket writes back the L2 the launch has just filled with u and v, and the
+// tickets serialise at ~12 ns each: 53 us for the launch at C2, against 10 + 4 us for these two; a dependent kernel
+// boundary costs 1.5 - 1.9 us on this GPU.)
+struct PostArgs {
+    const float *u_part;
+    float *u;
+    const float *v_part;
+    float *v;          // NULL: v aliases v_part (one z-chunk), only ||v||^2 is taken
+    double *scal;
+    const double *fold_rows;   // the preceding launch's partial rows
+    double *part;              // this launch's partial rows
+    long long S, vlen;
+    int n_urows, n_zchunks, nbu, nbv, n_fold_rows, flags;
+    double c1, c2, eps;
+};
+
+__global__ __launch_bounds__(256) void k_post_sweep(const PostArgs a) {
+    double uu = 0, vv = 0;
+    const int b = blockIdx.x;
+    if (b < a.nbu) {
+        if (a.flags & DFX_POST_U) {
+            const long long stride = (long long)a.nbu * 256;
+            const long long t0 = (long long)b * 256 + threadIdx.x;
+            const bool vec = (a.S % 4 == 0) && ((((uintptr_t)a.u_part | (uintptr_t)a.u) & 15) == 0);
+            if (vec) {
+                for (long long i = t0; i < a.S / 4; i += stride) {
+                    f4 sacc = ld4(a.u_part + 4 * i);
+                    for (int c = 1; c < a.n_urows; ++c) sacc += ld4(a.u_part + (long long)c * a.S + 4 * i);
+                    st4(a.u + 4 * i, sacc);
+                    uu += ((double)sacc.x * sacc.x + (double)sacc.y * sacc.y) + ((double)sacc.z * sacc.z + (double)sacc.w * sacc.w);
+                }
+            } else {
+                for (long long i = t0; i < a.S; i += stride) {
+                    float sacc = 0.f;
+                    for (int c = 0; c < a.n_urows; ++c) sacc += a.u_part[(long long)c * a.S + i];
+                    a.u[i] = sacc;
+                    uu += (double)sacc * (double)sacc;
+                }
+            }
+        }
+    } else if (a.flags & DFX_POST_V) {
+        const long long stride = (long long)a.nbv * 256;
+        const long long t0 = (long long)(b - a.nbu) * 256 + threadIdx.x;
+        const bool vec = (a.vlen % 4 == 0) && ((((uintptr_t)a.v_part | (uintptr_t)a.v) & 15) == 0);
+        if (vec) {
+            for (long long i = t0; i < a.vlen / 4; i += stride) {
+                f4 sacc = ld4(a.v_part + 4 * i);
+                if (a.v) {
+                    for (int c = 1; c < a.n_zchunks; ++c) sacc += ld4(a.v_part + (long long)c * a.vlen + 4 * i);
+                    st4(a.v + 4 * i, sacc);
+                }
+                vv += ((double)sacc.x * sacc.x + (double)sacc.y * sacc.y) + ((double)sacc.z * sacc.z + (double)sacc.w * sacc.w);
+            }
+        } else {
+            for (long long i = t0; i < a.vlen; i += stride) {
+                float sacc = a.v_part[i];
+                if (a.v) {
+                    for (int c = 1; c < a.n_zchunks; ++c) sacc += a.v_part[(long long)c * a.vlen + i];
+                    a.v[i] = sacc;
+                }
+                vv += (double)sacc * (double)sacc;
+            }
+        }
+    }
+    block_store3(uu, vv, 0.0, a.part + (long long)b * DFX_NPART);
+}
+
+__global__ __launch_bounds__(256) void k_post_fold(const PostArgs a) {
+    __shared__ double sh[256];
+    const int n_own = a.nbu + a.nbv;
+    double *s = a.scal;
+    if (a.flags & DFX_POST_U) {
+        const double r = fold_col(a.part, n_own, 0, sh);
+        if (threadIdx.x == 0) s[DFX_S_UU] = r;
+    }
+    if (a.flags & DFX_POST_V) {
+        const double r = fold_col(a.part, n_own, 1, sh);
+        if (threadIdx.x == 0) s[DFX_S_VV] = r;
+    }
+    if (a.flags & DFX_POST_FOLD_SWEEP) {
+        for (int k = 0; k < 3; ++k) {
+            const double r = fold_col(a.fold_rows, a.n_fold_rows, k, sh);
+            if (threadIdx.x == 0) s[DFX_S_PP + k] = r;       // PP, XX, XP are consecutive slots
+        }
+    }
+    if (a.flags & DFX_POST_FOLD_ADAM) {
+        for (int k = 0; k < 2; ++k) {
+            const double r = fold_col(a.fold_rows, a.n_fold_rows, k, sh);
+            if (threadIdx.x == 0) s[DFX_S_ADAM_DD + k] = r;  // ADAM_DD, ADAM_XX
+        }
+    }
+    if ((a.flags & DFX_POST_ALPHA) && threadIdx.x == 0) cg_alpha_body(s, a.c1, a.c2, a.eps);
+}
+
+// Everything a fused Adam iteration does in the small space BEFORE its 5-D pass, in one launch (fusion.py:332-338:
+// loss(), and the part of loss.backward() that lives on the cmos- and spc-sized arrays):
+//   A = -2 w1 mask1 (cmos - u) ; B = -2 w2 mask2 (spc - v)          d loss / d u, d loss / d v  (k_diff_scale)
+//   m1a <- lerp(m1a, A, 1-b1) ; m1b <- lerp(m1b, B, 1-b1)           exp_avg's two factors       (k_lerp)
+//   LOSS1 = w1 sum mask1 (cmos - u)^2 ; LOSS2 = w2 sum mask2 (spc - v)^2                        (k_reduce1<1>)
+struct PrepArgs {
+    const float *u, *cmos, *cmask;
+    float *A, *m1a;
+    long long n_u;
+    const float *v, *spc, *smask;
+    long long smask_n;
+    float *B, *m1b;
+    long long n_v;
+    float ca, cb, omb1;
+    double w1, w2;
+    double *part, *scal;
+    int nbu, nbv;
+};
+
+__global__ __launch_bounds__(256) void k_adam_prep(const PrepArgs a) {
+    double l1 = 0, l2 = 0;
+    const int b = blockIdx.x;
+    if (b < a.nbu) {
+        const long long stride = (long long)a.nbu * 256;
+        for (long long i = (long long)b * 256 + threadIdx.x; i < a.n_u; i += stride) {
+            const float d = a.cmos[i] - a.u[i];
+            float g = a.ca * d;
+            double w = 1.0;
+            if (a.cmask) {
+                const float mk = a.cmask[i];
+                g *= mk;
+                w = (double)mk;
+            }
+            l1 += w * (double)d * (double)d;
+            a.A[i] = g;
+            if (a.m1a) {
+                const float m = a.m1a[i];
+                a.m1a[i] = m + a.omb1 * (g - m);
+            }
+        }
+    } else {
+        const long long stride = (long long)a.nbv * 256;
+        for (long long i = (long long)(b - a.nbu) * 256 + threadIdx.x; i < a.n_v; i += stride) {
+            const float d = a.spc[i] - a.v[i];
+            float g = a.cb * d;
+            double w = 1.0;
+            if (a.smask) {
+                const float mk = a.smask[i % a.smask_n];   // the (x/r, y/r) mask repeats over (t, l)
+                g *= mk;
+                w = (double)mk;
+            }
+            l2 += w * (double)d * (double)d;
+            a.B[i] = g;
+            if (a.m1b) {
+                const float m = a.m1b[i];
+                a.m1b[i] = m + a.omb1 * (g - m);
+            }
+        }
+    }
+    block_store3(l1, l2, 0.0, a.part + (long long)b * DFX_NPART);
+}
+
+__global__ __launch_bounds__(256) void k_prep_fold(const double *part, int n_rows, double w1, double w2, double *scal) {
+    __shared__ double sh[256];
+    const double s1 = fold_col(part, n_rows, 0, sh), s2 = fold_col(part, n_rows, 1, sh);
+    if (threadIdx.x == 0) {
+        scal[DFX_S_LOSS1] = w1 * s1;
+        scal[DFX_S_LOSS2] = w2 * s2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Factored residual.  r0 = b - A x0 and every A p are sums of a (z,x,y) array broadcast over (t,l) and a
 // (t,l,x/r,y/r) array broadcast over z and the r x r block (fusion.py:423-430), so the CG residual always has the
@@ -917,29 +1116,19 @@ __global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, cons
     block_store3(0.0, a2, ab, part + (long long)blockIdx.x * DFX_NPART);
 }
 
-// RR = M * sum ra^2 + 2 * sum rb zab + nZ r^2 * sum rb^2 from the rows the two kernels above wrote
-__global__ __launch_bounds__(256) void k_resid_rr(const double *parts, int n_rows, double m, double zr2, double *s) {
-    __shared__ double sh[3][256];
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int b = threadIdx.x; b < n_rows; b += 256) {
-        s0 += parts[(long long)b * DFX_NPART + 0];
-        s1 += parts[(long long)b * DFX_NPART + 1];
-        s2 += parts[(long long)b * DFX_NPART + 2];
-    }
-    sh[0][threadIdx.x] = s0;
-    sh[1][threadIdx.x] = s1;
-    sh[2][threadIdx.x] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o)
-            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
-        __syncthreads();
-    }
+// One workgroup: RR = M * sum ra^2 + 2 * sum rb zab + nZ r^2 * sum rb^2 from the rows the two kernels above wrote
+// (torch.dot(r, r), fusion.py:437,447); with beta_mode >= 0 it also closes the iteration's scalar bookkeeping
+// (k_cg_beta; beta_mode = the deferred flag).
+__global__ __launch_bounds__(256) void k_resid_rr(const double *parts, int n_rows, double m, double zr2, double *s,
+                                                  int beta_mode, double eps) {
+    __shared__ double sh[256];
+    const double s0 = fold_col(parts, n_rows, 0, sh), s1 = fold_col(parts, n_rows, 1, sh), s2 = fold_col(parts, n_rows, 2, sh);
     if (threadIdx.x == 0) {
-        s[DFX_S_RA2] = sh[0][0];
-        s[DFX_S_RB2] = sh[1][0];
-        s[DFX_S_RAB] = sh[2][0];
-        s[DFX_S_RR] = m * sh[0][0] + 2.0 * sh[2][0] + zr2 * sh[1][0];
+        s[DFX_S_RA2] = s0;
+        s[DFX_S_RB2] = s1;
+        s[DFX_S_RAB] = s2;
+        s[DFX_S_RR] = m * s0 + 2.0 * s2 + zr2 * s1;
+        if (beta_mode >= 0) cg_beta_body(s, eps, beta_mode);
     }
 }
 
@@ -947,33 +1136,16 @@ __global__ void k_cg_start(double *s) {
     s[DFX_S_RSOLD] = s[DFX_S_RR];
     s[DFX_S_RSNEW] = s[DFX_S_RR];
     s[DFX_S_ALPHA] = 0.0;
+    s[DFX_S_ALPHA_LAST] = 0.0;
     s[DFX_S_BETA] = 0.0;
     s[DFX_S_TOL] = 0.0;
     s[DFX_S_ITER] = 0.0;
     s[DFX_S_NONFINITE] = isfinite(s[DFX_S_RR]) ? 0.0 : 1.0;
 }
 
-__global__ void k_cg_alpha(double *s, double c1, double c2, double eps) {
-    // float arithmetic where the reference has 0-dim fp32 tensors (fusion.py:444)
-    const float pap = (float)(c1 * s[DFX_S_UU] + c2 * s[DFX_S_VV]);
-    s[DFX_S_PAP] = (double)pap;
-    const float alpha = (float)s[DFX_S_RSOLD] / (pap + (float)eps);
-    s[DFX_S_ALPHA] = (double)alpha;
-}
+__global__ void k_cg_alpha(double *s, double c1, double c2, double eps) { cg_alpha_body(s, c1, c2, eps); }
 
-__global__ void k_cg_beta(double *s, double eps, int deferred) {
-    const double rsnew = s[DFX_S_RR];
-    s[DFX_S_RSNEW] = rsnew;
-    if (!isfinite(rsnew)) s[DFX_S_NONFINITE] += 1.0;
-    const double al = s[DFX_S_ALPHA];
-    const double pp = s[DFX_S_PP];
-    const double xx_new = deferred ? (s[DFX_S_XX] + 2.0 * al * s[DFX_S_XP] + al * al * pp) : s[DFX_S_XXNEW];
-    s[DFX_S_TOL] = fabs(al) * sqrt(pp) / sqrt(xx_new);
-    const float beta = (float)rsnew / ((float)s[DFX_S_RSOLD] + (float)eps);
-    s[DFX_S_BETA] = (double)beta;
-    s[DFX_S_RSOLD] = rsnew;
-    s[DFX_S_ITER] += 1.0;
-}
+__global__ void k_cg_beta(double *s, double eps, int deferred) { cg_beta_body(s, eps, deferred); }
 
 __global__ void k_recip(double *dst, const double *src, double num) { dst[0] = num / src[0]; }
 
@@ -1373,8 +1545,9 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
     }
     out->u_part_elems = (long long)(out->n_chunks / out->cpb) * q.S;   // one row per workgroup of the slab axis
     out->v_part_elems = (long long)out->n_zchunks * q.M * q.Ps;
-    long long rows = (long long)out->n_blocks * DFX_MAX_SLICES;
-    if (rows < DFX_EW_MAXBLOCKS) rows = DFX_EW_MAXBLOCKS;
+    // rows of the sweep's slices, then DFX_EW_MAXBLOCKS rows for dfx_post_sweep's own partials (which must not
+    // overlap the rows it folds); the element-wise entry points use rows [0, DFX_EW_MAXBLOCKS)
+    long long rows = (long long)out->n_blocks * DFX_MAX_SLICES + DFX_EW_MAXBLOCKS;
     out->part_elems = rows * DFX_NPART;
     return 0;
 }
@@ -1444,7 +1617,8 @@ static int sweep_impl(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float
         n_rows = nb;
     }
     // (pp, xx, xp) -> scal[PP], scal[XX], scal[XP] (consecutive slots), over the rows of every slice so far
-    if (!last) return 0;
+    // (last == DFX_LAST_NOFOLD: the rows are left for dfx_post_sweep, which folds them in its own launch)
+    if (!last || last == DFX_LAST_NOFOLD) return 0;
     return fold(part, n_rows, 3, scal + DFX_S_PP, 1.0, st);
 }
 
@@ -1467,7 +1641,7 @@ int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, floa
 
 static int resid_update_impl(const Geo &q, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
                              float coef_host, const double *coef_dev, int32_t accumulate, double *zab, double *scal,
-                             double *part, hipStream_t st) {
+                             double *part, int beta_mode, double eps, hipStream_t st) {
     const int groups = (int)((q.Ps + 15) / 16);
     const int nba = groups < DFX_EW_MAXBLOCKS / 2 ? groups : DFX_EW_MAXBLOCKS / 2;
     const int nbb = q.M < DFX_EW_MAXBLOCKS / 2 ? q.M : DFX_EW_MAXBLOCKS / 2;
@@ -1478,7 +1652,7 @@ static int resid_update_impl(const Geo &q, float *ra, float *rb, const float *A,
                        coef_host, coef_dev, accumulate, part + (long long)nba * DFX_NPART);
     DFX_LAUNCH_CHECK("dfx_resid_update(b)");
     hipLaunchKernelGGL(k_resid_rr, dim3(1), dim3(256), 0, st, (const double *)part, nba + nbb, (double)q.M,
-                       (double)q.nZ * q.r * q.r, scal);
+                       (double)q.nZ * q.r * q.r, scal, beta_mode, eps);
     DFX_LAUNCH_CHECK("dfx_resid_update(rr)");
     return 0;
 }
@@ -1490,8 +1664,18 @@ int dfx_resid_update(const dfx_geom *g, float *ra, float *rb, const float *A, co
     if (int rc = make_geo(g, &q)) return rc;
     if (!ra || !rb || !A || !B || !zab || !scal || !part) return fail(DFX_EINVAL, "dfx_resid_update: NULL buffer");
     if (q.Ps > 0x7fffffffLL) return fail(DFX_EINVAL, "dfx_resid_update: plane too large");
-    return resid_update_impl(q, ra, rb, A, B, sa, sb, coef_host, coef_dev, accumulate, zab, scal, part,
+    return resid_update_impl(q, ra, rb, A, B, sa, sb, coef_host, coef_dev, accumulate, zab, scal, part, -1, 0.0,
                              (hipStream_t)stream);
+}
+
+int dfx_resid_cg_step(const dfx_geom *g, float *ra, float *rb, const float *u, const float *v, double c1, double c2,
+                      double eps, int32_t deferred, double *zab, double *scal, double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (!ra || !rb || !u || !v || !zab || !scal || !part) return fail(DFX_EINVAL, "dfx_resid_cg_step: NULL buffer");
+    if (q.Ps > 0x7fffffffLL) return fail(DFX_EINVAL, "dfx_resid_cg_step: plane too large");
+    return resid_update_impl(q, ra, rb, u, v, (float)c1, (float)c2, -1.0f, scal + DFX_S_ALPHA, 1, zab, scal, part,
+                             deferred ? 1 : 0, eps, (hipStream_t)stream);
 }
 
 int dfx_resid_update_noalloc(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa,
@@ -1509,7 +1693,7 @@ int dfx_resid_update_noalloc(const dfx_geom *g, float *ra, float *rb, const floa
     // every element the kernels read is written earlier in this same call (zab[0, Ps) by k_resid_az, each partial row
     // by its workgroup), so nothing needs clearing between calls; calls overlapping on one GPU would race on it
     return resid_update_impl(q, ra, rb, A, B, sa, sb, coef_host, coef_dev, accumulate, scratch, scal,
-                             scratch + DFX_NOALLOC_MAX_PS, st);
+                             scratch + DFX_NOALLOC_MAX_PS, -1, 0.0, st);
 }
 
 int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in, const float *A,
@@ -1559,7 +1743,7 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     AdamArgs a{x, m1, m2, m1a, m1b, A, B, mask, u_part, v_part, part, (float)beta1, (float)beta2,
                (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-               (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), non_neg ? 1 : 0, q, pl->steps, pl->cpb};
+               (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (non_neg & DFX_ADAM_NONNEG) ? 1 : 0, q, pl->steps, pl->cpb};
     int n_rows;
     if (pl->fast) {
         if (!aligned16(x) || !aligned16(m1) || !aligned16(m2) || !aligned16(A) || !aligned16(mask) ||
@@ -1589,6 +1773,7 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
                            v_part, q);
         DFX_LAUNCH_CHECK("dfx_adam_step(generic v)");
     }
+    if (non_neg & DFX_ADAM_NOFOLD) return 0;   // the rows are left for dfx_post_sweep(DFX_POST_FOLD_ADAM)
     return fold(part, n_rows, 2, scal + DFX_S_ADAM_DD, 1.0, st);   // (DD, XX) -> consecutive slots
 }
 
@@ -1609,11 +1794,80 @@ int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, cons
                      v_part, part, stream);
 }
 
+int dfx_adam_prep(const float *u, const float *cmos, const float *cmask, float *A, float *m1a, int64_t n_u,
+                  const float *v, const float *spc, const float *smask, int64_t smask_n, float *B, float *m1b,
+                  int64_t n_v, double w1, double w2, double lerp_weight, double *scal, double *part, void *stream) {
+    if (!u || !cmos || !A || !v || !spc || !B || !scal || !part || n_u <= 0 || n_v <= 0 ||
+        (smask && (smask_n <= 0 || n_v % smask_n)) || ((m1a == nullptr) != (m1b == nullptr)))
+        return fail(DFX_EINVAL, "dfx_adam_prep: bad argument");
+    PrepArgs a{u, cmos, cmask, A, m1a, (long long)n_u, v, spc, smask, (long long)(smask ? smask_n : 1), B, m1b,
+               (long long)n_v, (float)(-2.0 * w1), (float)(-2.0 * w2), (float)lerp_weight, w1, w2, part, scal,
+               ew_blocks(n_u, 4) > 512 ? 512 : ew_blocks(n_u, 4), ew_blocks(n_v, 4) > 1024 ? 1024 : ew_blocks(n_v, 4)};
+    hipLaunchKernelGGL(k_adam_prep, dim3(a.nbu + a.nbv), dim3(256), 0, (hipStream_t)stream, a);
+    DFX_LAUNCH_CHECK("dfx_adam_prep");
+    hipLaunchKernelGGL(k_prep_fold, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)part, a.nbu + a.nbv, w1,
+                       w2, scal);
+    DFX_LAUNCH_CHECK("dfx_adam_prep(fold)");
+    return 0;
+}
+
 int dfx_lerp(float *m, const float *g, int64_t n, double weight, void *stream) {
     if (!m || !g || n <= 0) return fail(DFX_EINVAL, "dfx_lerp: bad argument");
     hipLaunchKernelGGL(k_lerp, dim3(ew_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, m, g, (long long)n,
                        (float)weight);
     DFX_LAUNCH_CHECK("dfx_lerp");
+    return 0;
+}
+
+int dfx_post_sweep(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, const float *v_part,
+                   float *v, double *scal, double *part, int32_t n_slices, int32_t flags, double c1, double c2,
+                   double eps, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (int rc = check_plan(q, pl)) return rc;
+    if (!scal || !part) return fail(DFX_EINVAL, "dfx_post_sweep: NULL buffer");
+    if ((flags & DFX_POST_U) && (!u_part || !u)) return fail(DFX_EINVAL, "dfx_post_sweep: DFX_POST_U needs u_part, u");
+    if ((flags & DFX_POST_V) && !v_part) return fail(DFX_EINVAL, "dfx_post_sweep: DFX_POST_V needs v_part");
+    if ((flags & DFX_POST_V) && pl->n_zchunks > 1 && !v && !(flags & DFX_POST_V_SUMMED))
+        return fail(DFX_EINVAL, "dfx_post_sweep: more than one z-chunk: v needed to hold the sum");
+    if ((flags & DFX_POST_FOLD_SWEEP) && (flags & DFX_POST_FOLD_ADAM))
+        return fail(DFX_EINVAL, "dfx_post_sweep: fold either the sweep's or the Adam step's rows");
+    if (n_slices < 1 || n_slices > DFX_MAX_SLICES) return fail(DFX_EINVAL, "dfx_post_sweep: bad n_slices");
+    PostArgs a;
+    a.u_part = u_part;
+    a.u = u;
+    // DFX_POST_V_SUMMED: `v_part` already holds the summed (and, when sharded, all-reduced) v: only ||v||^2 is taken
+    const bool summed = (flags & DFX_POST_V_SUMMED) || pl->n_zchunks == 1;
+    a.v_part = v_part;
+    a.v = summed ? nullptr : v;
+    a.scal = scal;
+    a.fold_rows = part;
+    a.part = part + (long long)pl->n_blocks * DFX_MAX_SLICES * DFX_NPART;   // behind the sweep's rows (dfx_plan.part_elems)
+    a.S = q.S;
+    a.vlen = (long long)q.M * q.Ps;
+    a.n_urows = pl->n_chunks / pl->cpb;
+    a.n_zchunks = pl->n_zchunks;
+    a.nbu = 0;
+    a.nbv = 0;
+    if (flags & DFX_POST_U) {
+        long long nb = (q.S / 4 + 255) / 256;
+        a.nbu = (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
+    }
+    if (flags & DFX_POST_V) {
+        long long nb = (a.vlen / 4 + 1023) / 1024;
+        a.nbv = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    }
+    a.n_fold_rows = (pl->fast ? n_slices : 1) * pl->n_blocks;
+    a.flags = flags;
+    a.c1 = c1;
+    a.c2 = c2;
+    a.eps = eps;
+    if (flags & (DFX_POST_U | DFX_POST_V)) {
+        hipLaunchKernelGGL(k_post_sweep, dim3(a.nbu + a.nbv), dim3(256), 0, (hipStream_t)stream, a);
+        DFX_LAUNCH_CHECK("dfx_post_sweep");
+    }
+    hipLaunchKernelGGL(k_post_fold, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    DFX_LAUNCH_CHECK("dfx_post_sweep(fold)");
     return 0;
 }
 

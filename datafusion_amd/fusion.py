@@ -300,25 +300,30 @@ class FusionCG(Fusion):
             k = self.k
             k.u.copy_(saved[0]), k.v.copy_(saved[1]), k.scal[cabi.S_UU:cabi.S_XP + 1].copy_(saved[2])
 
-    def _sweep(self, mode) -> None:
-        """One pass over x, r, p.  When the volume is z-sharded the pass is cut into `comm_slices` launches along
-        the slab axis and the all-reduce of each finished band of v (the RD partials, the one real exchange,
-        SURVEY 8e) is started on RCCL's stream while the next band is still being swept."""
+    def _sweep(self, mode, eps: float | None = None) -> None:
+        """One pass over x, (r,) p and everything that follows it: u(p), v(p), UU, VV, PP, XX, XP - and, when `eps` is
+        given, alpha of the next iteration (fusion.py:444).
+        One GPU: the 5-D launch + ONE dfx_post_sweep launch.
+        z-sharded: the pass is cut into `comm_slices` launches along the slab axis and the all-reduce of each
+        finished band of v (the RD partials, the one real exchange) is started on RCCL's stream while the
+        next band is still being swept; u, UU and the scalar partials take one dfx_post_sweep launch, their all-reduce
+        (4 doubles) follows the last band's, and ||v||^2 (+ alpha) a second one once v is complete."""
         k, c = self.k, self.comm
         fact = self.residual == "factored"
+        c1, c2 = self._coefs()
+        al = cabi.POST_ALPHA if eps is not None else 0
+        e = 0.0 if eps is None else float(eps)
         if c.size > 1 or c._always:
             pending = []
             k.sweep(mode, self.x, self._r, self._p, slices=self.comm_slices,
-                    after_slice=lambda rows: pending.append(c.sum_async(rows)), factored=fact)
+                    after_slice=lambda rows: pending.append(c.sum_async(rows)), factored=fact, fold=False)
+            k.post_sweep(cabi.POST_U | cabi.POST_FOLD_SWEEP)
             c.wait(pending)
+            c.sum_(k.scal[cabi.S_UU:cabi.S_XP + 1])       # UU, PP, XX, XP partials
+            k.post_sweep(cabi.POST_V | cabi.POST_V_SUMMED | al, c1, c2, e)    # VV identical on every rank
         else:
-            k.sweep(mode, self.x, self._r, self._p, factored=fact)
-
-    def _finish_projection(self) -> None:
-        """After _sweep (v already summed over shards): ||v||^2 and the scalar partials."""
-        k, c = self.k, self.comm
-        k.sqnorm_v()                                  # VV identical on every rank
-        c.sum_(k.scal[cabi.S_UU:cabi.S_XP + 1])       # UU, PP, XX, XP partials
+            k.sweep(mode, self.x, self._r, self._p, factored=fact, fold=False)
+            k.post_sweep(cabi.POST_U | cabi.POST_V | cabi.POST_FOLD_SWEEP | al, c1, c2, e)
 
     def _balance_gauge(self, du, dv, c1, c2):
         """The split r = ra + rb is not unique: a (x/r, y/r) array g can be moved between the two (ra + g, rb - g).
@@ -380,7 +385,6 @@ class FusionCG(Fusion):
         c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
         k.cg_start()                                                            # rsold (fusion.py:437)
         self._sweep(cabi.SWEEP_PINIT)                                           # p = r (fusion.py:436)
-        self._finish_projection()
         self._pending_x = False
         self._stopped = False
 
@@ -392,6 +396,9 @@ class FusionCG(Fusion):
         c1, c2 = self._coefs()
         x, rv, pv = self.x, self._r, self._p
         deferred = self.defer_x
+        one_gpu = not (c.size > 1 or c._always)
+        # alpha of the first iteration of this call; every later one is computed by the launch that follows the sweep
+        k.cg_alpha(c1, c2, eps)                                                 # fusion.py:443-444
         if history is not None and deferred:
             # a per-iteration loss needs the current x, and the two schedules cannot alternate (SWEEP_P leaves no
             # ||x||^2, <x,p> for a deferred tolerance): construct with defer_x=False (verbose=True does)
@@ -400,18 +407,20 @@ class FusionCG(Fusion):
             if self._stopped:
                 break
             self.curr_iter += 1
-            k.cg_alpha(c1, c2, eps)                                             # fusion.py:443-444
             if not deferred:
                 k.axpy(x, pv, 1.0, cabi.S_ALPHA)                                # fusion.py:445
                 c.sum_(k.scal[cabi.S_XXNEW:cabi.S_XXNEW + 1])
             else:
                 self._pending_x = True
-            if self.residual == "factored":                                     # fusion.py:446-447
-                k.resid_update(k.u, k.v, c1, c2, -1.0, cabi.S_ALPHA, True)
+            if self.residual == "factored" and one_gpu:                         # fusion.py:446-448, 455-456
+                k.resid_cg_step(c1, c2, eps, deferred)                          # r update, rsnew, tol, beta: 2 launches
             else:
-                k.bcast(rv, rv, k.u, k.v, None, c1, c2, -1.0, cabi.S_ALPHA)
-            c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
-            k.cg_beta(eps, deferred)                                            # rsnew, tol, beta
+                if self.residual == "factored":                                 # fusion.py:446-447
+                    k.resid_update(k.u, k.v, c1, c2, -1.0, cabi.S_ALPHA, True)
+                else:
+                    k.bcast(rv, rv, k.u, k.v, None, c1, c2, -1.0, cabi.S_ALPHA)
+                c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
+                k.cg_beta(eps, deferred)                                        # rsnew, tol, beta
             if self.tol is not None or self.verbose or history is not None:
                 s = k.scal.cpu()                                                # one sync, as fusion.py:448
                 assert bool(s[cabi.S_NONFINITE] == 0), "Conjugate gradient diverged"
@@ -421,9 +430,8 @@ class FusionCG(Fusion):
             if history is not None:                                             # fusion.py:458-478
                 l1, l2 = self.loss()                                            # x is current: textbook schedule
                 history[i] = [float(l1), float(l2), float(l1) + float(l2), float(s[cabi.S_RSNEW])]
-            self._sweep(cabi.SWEEP_XP if deferred else cabi.SWEEP_P)            # fusion.py:445,455
+            self._sweep(cabi.SWEEP_XP if deferred else cabi.SWEEP_P, eps)       # fusion.py:445,455 (+ next alpha)
             self._pending_x = False
-            self._finish_projection()
 
     @torch.no_grad()
     def finish(self) -> None:
@@ -496,7 +504,7 @@ class FusionAdam(Fusion):
         self.fused = fused
         self.moment1 = moment1
         self.betas, self.adam_eps = betas, adam_eps
-        self._m1 = self._m2 = self._m1a = self._m1b = None
+        self._m1 = self._m2 = self._m1a = self._m1b = self._gA = self._gB = None
         self._adam_step = 0
 
     def loss_autograd(self, mask_grad: bool = False):
@@ -530,20 +538,25 @@ class FusionAdam(Fusion):
                 t.zero_()
         self._adam_step = 0
         self._project(x)                                   # u(x), v(x) for the first loss / gradient
+        cmask = self._cmask_loc if self.mask_noise else None
+        smask = self._smask_f if self.mask_noise else None
+        if self._gA is None:
+            self._gA, self._gB = torch.empty_like(k.u), torch.empty_like(k.v)
+        A, B = self._gA, self._gB
         for i in range(max_iterations):
             self.curr_iter += 1
-            l1, l2 = self._losses_from_uv()                                     # fusion.py:332
-            # d loss / d u and d loss / d v (autograd of fusion.py:216-232), small arrays
-            A = k.diff_scale(self._cmos_loc, k.u, self._cmask_loc if self.mask_noise else None, -2.0 * w1)
-            B = k.diff_scale(self.spc, k.v, self._smask_f if self.mask_noise else None, -2.0 * w2)
             self._adam_step += 1
-            if fact:                                    # exp_avg.lerp_(grad, 1 - beta1) on its two factors
-                k.lerp(self._m1a, A, 1.0 - self.betas[0])
-                k.lerp(self._m1b, B, 1.0 - self.betas[0])
-            k.adam_step(x, self._m1, self._m2, A, B,
-                        self._cmask_loc if self.mask_noise else None,                  # fusion.py:274-278
-                        lr, self.betas[0], self.betas[1], self.adam_eps, self._adam_step, non_neg,
-                        m1a=self._m1a, m1b=self._m1b)
+            # one launch: the losses (fusion.py:332), d loss / d u and d loss / d v (autograd of fusion.py:216-232) and
+            # exp_avg.lerp_(grad, 1 - beta1) on the first moment's two factors - all on the small arrays
+            k.adam_prep(self._cmos_loc, cmask, self.spc, smask, A, B, self._m1a, self._m1b, w1, w2,
+                        1.0 - self.betas[0])
+            if history is not None:
+                c.sum_(k.scal[cabi.S_LOSS1:cabi.S_LOSS1 + 1])                   # the cmos term is a sum over shards
+                l1, l2 = k.scal[cabi.S_LOSS1].float(), k.scal[cabi.S_LOSS2].float()
+            # one 5-D pass (mask: fusion.py:274-278), then one launch for u(x), v(x), ||dx||^2, ||x||^2
+            k.adam_step(x, self._m1, self._m2, A, B, cmask, lr, self.betas[0], self.betas[1], self.adam_eps,
+                        self._adam_step, non_neg, m1a=self._m1a, m1b=self._m1b, fold=False)
+            k.post_sweep(cabi.POST_U | cabi.POST_V | cabi.POST_FOLD_ADAM)
             c.sum_(k.v)
             tolerance = None
             if self.tol is not None:                                            # fusion.py:348

@@ -59,6 +59,7 @@ class HipKernels:
         self.v = self._v_own if self._v_own is not None else self.v_part.view(n_t, n_l, self.Xs, self.Ys)
         self.ra = self.rb = self.zab = None   # factored residual (new_factored_residual)
         self.timing = None   # bench.py sets a dict: name -> list of (start, end) torch.cuda.Event pairs
+        self.timing_names = None   # ... and, to time only some entry points (an event pair costs ~2 us of stream time), their names
 
     # -- helpers --------------------------------------------------------------------------
     def _stream(self):
@@ -69,7 +70,7 @@ class HipKernels:
 
     def _timed(self, name, fn, *args):
         """Launch through `fn`; when self.timing is set, bracket it with HIP events on the launch stream."""
-        if self.timing is None:
+        if self.timing is None or (self.timing_names is not None and name not in self.timing_names):
             return fn(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(self.device))
@@ -180,12 +181,15 @@ class HipKernels:
 
     # -- 5-D passes -----------------------------------------------------------------------
     @_on_device
-    def sweep(self, mode: int, x, r=None, p=None, slices: int = 1, after_slice=None, factored: bool = False) -> None:
+    def sweep(self, mode: int, x, r=None, p=None, slices: int = 1, after_slice=None, factored: bool = False,
+              fold: bool = True) -> None:
         """u(.) -> self.u (+UU), local v partial -> self.v, PP/XX/XP -> scal.
         factored=True: r is not a 5-D array but self.ra + self.rb (dfx_sweep_factored); pass r=None.
         slices > 1 cuts the pass along the slab axis into that many launches (fast plans; at most cpb);
         after_slice(v_rows) is called after each one with the rows of self.v (viewed (nT*nL, Xs*Ys)) that
-        are final - the hook the z-sharded solver uses to start their all-reduce while the sweep goes on."""
+        are final - the hook the z-sharded solver uses to start their all-reduce while the sweep goes on.
+        fold=False: only the 5-D launch(es) (and, with after_slice, the per-band v sums) are issued; u, v, UU and
+        PP/XX/XP are left to ONE post_sweep() launch."""
         self._chk(x, r, p)
         for t in (x, r, p):
             assert t is None or t.numel() == self.N
@@ -198,32 +202,49 @@ class HipKernels:
         vrows = self.v.view(self.M, self.Xs * self.Ys)
         if factored:
             assert r is None and self.ra is not None and mode != cabi.SWEEP_PROJECT
+        self._last_slices = k
+        final = cabi.LAST_FOLD if fold else cabi.LAST_NOFOLD
         for j in range(k):
             c_lo, c_hi = bounds[j], bounds[j + 1]
+            last = final if j == k - 1 else cabi.LAST_NO
             if factored:
                 cabi.check(self._timed(f"sweep{mode}f", self.lib.dfx_sweep_factored, mode, g, pl, cabi.ptr(x),
                                        cabi.ptr(self.ra), cabi.ptr(self.rb), cabi.ptr(p), cabi.ptr(self.scal),
                                        cabi.ptr(self.u_part), cabi.ptr(self.v_part), cabi.ptr(self.part), c_lo, c_hi,
-                                       j, int(j == k - 1), s), "dfx_sweep_factored")
+                                       j, last, s), "dfx_sweep_factored")
             else:
                 cabi.check(self._timed(f"sweep{mode}", self.lib.dfx_sweep_chunks, mode, g, pl, cabi.ptr(x),
                                        cabi.ptr(r), cabi.ptr(p), cabi.ptr(self.scal), cabi.ptr(self.u_part),
-                                       cabi.ptr(self.v_part), cabi.ptr(self.part), c_lo, c_hi, j, int(j == k - 1), s),
+                                       cabi.ptr(self.v_part), cabi.ptr(self.part), c_lo, c_hi, j, last, s),
                            "dfx_sweep_chunks")
             m_lo, m_hi = min(c_lo * P.steps * gz, self.M), min(c_hi * P.steps * gz, self.M)
-            if m_hi <= m_lo:
-                continue
+            if m_hi <= m_lo or (not fold and after_slice is None):
+                continue                                  # post_sweep() sums the z-chunks of v in its own launch
             if self._v_own is not None:
                 cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), m_lo, m_hi, s),
                            "dfx_reduce_v")
             if after_slice is not None:
                 after_slice(vrows[m_lo:m_hi])
-        cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
-                                         cabi.ptr(self.part), s), "dfx_reduce_u")
+        if fold:
+            cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
+                                             cabi.ptr(self.part), s), "dfx_reduce_u")
+
+    @_on_device
+    def post_sweep(self, flags: int, c1: float = 0.0, c2: float = 0.0, eps: float = 0.0) -> None:
+        """ONE launch for what follows a sweep(fold=False) or adam_step(fold=False): u and UU (POST_U), v and VV
+        (POST_V; with POST_V_SUMMED self.v is already final, e.g. all-reduced, and only VV is taken), the scalar
+        partials of the 5-D launch (POST_FOLD_SWEEP / POST_FOLD_ADAM), alpha of the next iteration (POST_ALPHA)."""
+        g, pl = self._g()
+        summed = bool(flags & cabi.POST_V_SUMMED)
+        cabi.check(self._timed("post", self.lib.dfx_post_sweep, g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u),
+                               cabi.ptr(self.v if summed else self.v_part),
+                               None if summed or self._v_own is None else cabi.ptr(self._v_own),
+                               cabi.ptr(self.scal), cabi.ptr(self.part), getattr(self, "_last_slices", 1), flags,
+                               c1, c2, eps, self._stream()), "dfx_post_sweep")
 
     @_on_device
     def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step: int, non_neg: bool, m1a=None,
-                  m1b=None) -> None:
+                  m1b=None, fold: bool = True) -> None:
         """One fused Adam iteration: x, m2 (and m1) in place; u(x_new) -> self.u, local v partial -> self.v;
         ADAM_DD = ||dx||^2, ADAM_XX = ||x_new||^2.  m1=None: the first moment is mask * (m1a + m1b), already advanced
         by lerp() for this step (dfx_adam_step_factored)."""
@@ -232,7 +253,9 @@ class HipKernels:
         assert A.numel() == self.S and B.numel() == self.M * self.Xs * self.Ys and (mask is None or mask.numel() == self.S)
         g, pl = self._g()
         s = self._stream()
-        tail = (cabi.ptr(m2), cabi.ptr(A), cabi.ptr(B), cabi.ptr(mask), lr, beta1, beta2, eps, step, int(non_neg),
+        flags = (cabi.ADAM_NONNEG if non_neg else 0) | (0 if fold else cabi.ADAM_NOFOLD)
+        self._last_slices = 1
+        tail = (cabi.ptr(m2), cabi.ptr(A), cabi.ptr(B), cabi.ptr(mask), lr, beta1, beta2, eps, step, flags,
                 cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part), cabi.ptr(self.part), s)
         if m1 is not None:
             cabi.check(self._timed("adam", self.lib.dfx_adam_step, g, pl, cabi.ptr(x), cabi.ptr(m1), *tail),
@@ -241,11 +264,26 @@ class HipKernels:
             assert m1a.numel() == self.S and m1b.numel() == self.M * self.Xs * self.Ys
             cabi.check(self._timed("adamf", self.lib.dfx_adam_step_factored, g, pl, cabi.ptr(x), cabi.ptr(m1a),
                                    cabi.ptr(m1b), *tail), "dfx_adam_step_factored")
+        if not fold:
+            return                                        # post_sweep(POST_U | POST_V | POST_FOLD_ADAM) follows
         cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
                                          cabi.ptr(self.part), s), "dfx_reduce_u")
         if self._v_own is not None:
             cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), 0, self.M, s),
                        "dfx_reduce_v")
+
+    @_on_device
+    def adam_prep(self, cmos, cmask, spc, smask, A, B, m1a, m1b, w1: float, w2: float, lerp_weight: float) -> None:
+        """The small-space half of a fused Adam iteration in one launch: A, B (d loss / d u, d loss / d v from
+        self.u, self.v), the lerp of the first moment's factors (m1a, m1b; None: skip), LOSS1, LOSS2."""
+        self._chk(cmos, cmask, spc, smask, A, B, m1a, m1b)
+        assert cmos.numel() == A.numel() == self.S and spc.numel() == B.numel() == self.M * self.Xs * self.Ys
+        assert cmask is None or cmask.numel() == self.S
+        assert smask is None or spc.numel() % smask.numel() == 0
+        cabi.check(self._timed("prep", self.lib.dfx_adam_prep, cabi.ptr(self.u), cabi.ptr(cmos), cabi.ptr(cmask),
+                               cabi.ptr(A), cabi.ptr(m1a), self.S, cabi.ptr(self.v), cabi.ptr(spc), cabi.ptr(smask),
+                               0 if smask is None else smask.numel(), cabi.ptr(B), cabi.ptr(m1b), B.numel(), w1, w2,
+                               lerp_weight, cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_adam_prep")
 
     @_on_device
     def lerp(self, m, g, weight: float) -> None:
@@ -284,6 +322,16 @@ class HipKernels:
                                cabi.ptr(B), sa, sb, coef_host, None if coef_slot is None else self.slot_ptr(coef_slot),
                                int(accumulate), cabi.ptr(self.zab), cabi.ptr(self.scal), cabi.ptr(self.part),
                                self._stream()), "dfx_resid_update")
+
+    @_on_device
+    def resid_cg_step(self, c1: float, c2: float, eps: float, deferred: bool) -> None:
+        """The small-space half of a CG iteration on one GPU, two launches: ra -= ALPHA c1 u ; rb -= ALPHA c2 v ; RR ;
+        then dfx_cg_beta's bookkeeping (RSNEW, TOL, BETA, ...) by the last workgroup of the second launch."""
+        assert self.ra is not None
+        g, _ = self._g()
+        cabi.check(self._timed("resid", self.lib.dfx_resid_cg_step, g, cabi.ptr(self.ra), cabi.ptr(self.rb),
+                               cabi.ptr(self.u), cabi.ptr(self.v), c1, c2, eps, int(deferred), cabi.ptr(self.zab),
+                               cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_resid_cg_step")
 
     @_on_device
     def resid_update_noalloc(self, A, B, sa: float, sb: float, coef_host: float, coef_slot: int | None,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 113
+#define DFX_VERSION 120
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -50,7 +50,7 @@ typedef struct dfx_plan {
     int32_t zs;          /* planes per z-chunk: ceil(nZ / n_zchunks) <= zc (chunks are balanced) */
     int64_t u_part_elems;    /* floats: (n_chunks / cpb) * nZ*X*Y: one row per workgroup of the slab axis */
     int64_t v_part_elems;    /* floats: n_zchunks * nT*nL*Xs*Ys */
-    int64_t part_elems;      /* doubles: max(n_blocks * DFX_MAX_SLICES, DFX_EW_MAXBLOCKS) * DFX_NPART */
+    int64_t part_elems;      /* doubles: (n_blocks * DFX_MAX_SLICES + DFX_EW_MAXBLOCKS) * DFX_NPART */
 } dfx_plan;
 
 /* Slots of the device-resident state `scal` (double[DFX_NSCAL]). */
@@ -72,12 +72,26 @@ enum {
     DFX_S_ADAM_DD = 19, /* ||x_new - x_old||^2 of the last dfx_adam_step              */
     DFX_S_ADAM_XX = 20, /* ||x_new||^2 of the last dfx_adam_step                      */
     DFX_S_RA2 = 21, DFX_S_RB2 = 22, DFX_S_RAB = 23, /* sum ra^2, sum rb^2, sum rb*zab of the last dfx_resid_update */
+    DFX_S_ALPHA_LAST = 24, /* the alpha of the iteration dfx_cg_beta closed (ALPHA is renewed right after the sweep) */
     DFX_NSCAL = 32
 };
 #define DFX_NPART 4          /* doubles per workgroup row of `part` */
 #define DFX_EW_MAXBLOCKS 2048 /* grid cap of the element-wise kernels */
 #define DFX_MAX_SLICES 16     /* most launches one sweep may be cut into (dfx_sweep_chunks) */
 #define DFX_NOALLOC_MAX_PS 65536 /* largest (X/r)*(Y/r) dfx_resid_update_noalloc accepts (its static scratch) */
+
+/* `last` argument of dfx_sweep_chunks / dfx_sweep_factored */
+enum { DFX_LAST_NO = 0, DFX_LAST_FOLD = 1, /* final slice: fold PP, XX, XP with a one-workgroup launch */
+       DFX_LAST_NOFOLD = 2 /* final slice: leave the partial rows to dfx_post_sweep(DFX_POST_FOLD_SWEEP) */ };
+/* dfx_post_sweep flags */
+enum { DFX_POST_U = 1,           /* u = sum of the u_part rows, UU                                            */
+       DFX_POST_V = 2,           /* v = sum of the v_part z-chunks (if more than one), VV                     */
+       DFX_POST_V_SUMMED = 4,    /* with DFX_POST_V: `v_part` is the finished v (e.g. after the all-reduce)    */
+       DFX_POST_FOLD_SWEEP = 8,  /* PP, XX, XP from the rows of a sweep issued with DFX_LAST_NOFOLD            */
+       DFX_POST_FOLD_ADAM = 16,  /* ADAM_DD, ADAM_XX from the rows of dfx_adam_step*(DFX_ADAM_NOFOLD)          */
+       DFX_POST_ALPHA = 32 };    /* then PAP, ALPHA of the next iteration (dfx_cg_alpha)                        */
+/* `non_neg` argument of dfx_adam_step*: bit flags */
+enum { DFX_ADAM_NONNEG = 1, DFX_ADAM_NOFOLD = 2 };
 
 /* sweep modes */
 enum {
@@ -143,6 +157,23 @@ int dfx_resid_update_noalloc(const dfx_geom *g, float *ra, float *rb, const floa
                              float sb, float coef_host, const double *coef_dev, int32_t accumulate, double *scal,
                              void *stream);
 
+/* One CG iteration's small-space half in three launches (fusion.py:446-448,455-456 and the tolerance of
+ * fusion.py:244-252): ra -= ALPHA*c1*u ; rb -= ALPHA*c2*v (ALPHA read from scal) ; then, in the one-workgroup launch
+ * that folds RR = ||r||^2 by the identity above, dfx_cg_beta's bookkeeping (RSNEW, NONFINITE, TOL, BETA, RSOLD, ITER).
+ * One-GPU path: a z-sharded solve all-reduces RR between dfx_resid_update and dfx_cg_beta. */
+int dfx_resid_cg_step(const dfx_geom *g, float *ra, float *rb, const float *u, const float *v, double c1, double c2,
+                      double eps, int32_t deferred, double *zab, double *scal, double *part, void *stream);
+
+/* Everything that follows a sweep, in TWO launches (flags above) instead of seven: one many-workgroup pass for the
+ * last stage of the T, S sums (u, UU: dfx_reduce_u), of the D sum (v: dfx_reduce_v) and ||v||^2 (dfx_sqnorm) of
+ * fusion.py:44-51,89-98,444; one one-workgroup launch that folds those partials, the sweep's (or fused Adam step's)
+ * per-workgroup scalar partials, and computes alpha (fusion.py:444, dfx_cg_alpha) - same arithmetic, fixed order.
+ * `part` is the buffer the preceding sweep wrote its rows into; n_slices = the number of launches that sweep was cut
+ * into.  v may be NULL with one z-chunk (v_part IS v). */
+int dfx_post_sweep(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, const float *v_part,
+                   float *v, double *scal, double *part, int32_t n_slices, int32_t flags, double c1, double c2,
+                   double eps, void *stream);
+
 /* out = (in ? in : 0) + coef * mask * (sa * A[z,x,y] + sb * B[t,l,x/r,y/r]),
  * coef = coef_host * (coef_dev ? *coef_dev : 1); mask (nZ,X,Y) optional (NULL = ones).
  * Broadcast-on-read adjoints: replaces T.T, S.T, D.T (fusion.py:36-42), R.T (fusion.py:78-87),
@@ -159,7 +190,8 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
  * clone + norms of fusion.py:329,348 and the next iteration's T,S,D,R forward fusion.py:226-232):
  *   g = mask * (A[z,x,y] + B[t,l,x/r,y/r]);  m1, m2, x updated in place (6N words);
  *   u_part, v_part <- projections of the NEW x;  scal[ADAM_DD] = ||dx||^2, scal[ADAM_XX] = ||x||^2.
- * `step` is the 1-based Adam step count (bias corrections are computed on the host in double). */
+ * `step` is the 1-based Adam step count (bias corrections are computed on the host in double).
+ * `non_neg`: DFX_ADAM_NONNEG (the clamp) | DFX_ADAM_NOFOLD (leave ADAM_DD, ADAM_XX to dfx_post_sweep). */
 int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, float *m2, const float *A,
                   const float *B, const float *mask, double lr, double beta1, double beta2, double eps, int32_t step,
                   int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream);
@@ -174,6 +206,15 @@ int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, cons
                            float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
                            double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
                            float *v_part, double *part, void *stream);
+/* The small-space half of one fused Adam iteration in ONE launch (fusion.py:332-338: loss(), and what
+ * loss.backward() does on the cmos- and spc-sized arrays):
+ *   A[i] = -2 w1 cmask[i] (cmos[i] - u[i]), i < n_u ;  B[i] = -2 w2 smask[i % smask_n] (spc[i] - v[i]), i < n_v
+ *   (masks optional, fusion.py:216-223) ; m1a, m1b (both or neither) advanced by lerp(., A / B, lerp_weight) ;
+ *   scal[LOSS1] = w1 sum cmask (cmos - u)^2, scal[LOSS2] = w2 sum smask (spc - v)^2  (fusion.py:226-232).
+ * Same arithmetic as dfx_diff_scale + dfx_lerp + dfx_sqdiff, which it replaces (8 launches -> 2). */
+int dfx_adam_prep(const float *u, const float *cmos, const float *cmask, float *A, float *m1a, int64_t n_u,
+                  const float *v, const float *spc, const float *smask, int64_t smask_n, float *B, float *m1b,
+                  int64_t n_v, double w1, double w2, double lerp_weight, double *scal, double *part, void *stream);
 /* m[i] += (float)weight * (g[i] - m[i]), i < n  (torch.lerp_ as torch.optim.Adam applies it to exp_avg inside
  * optimizer.step(), fusion.py:340). */
 int dfx_lerp(float *m, const float *g, int64_t n, double weight, void *stream);

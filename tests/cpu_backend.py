@@ -60,7 +60,27 @@ class CpuStandIn:
         self.v.copy_(a.sum(2).reshape(n_t, n_l, self.Xs, self.r, self.Ys, self.r).sum((3, 5)))
         self.scal[cabi.S_UU] = (self.u.double() ** 2).sum()
 
-    def sweep(self, mode, x, r=None, p=None, slices=1, after_slice=None, factored=False):
+    def post_sweep(self, flags, c1=0.0, c2=0.0, eps=0.0):
+        # u, UU and the scalar partials are already final here (the stand-in's sweep / adam_step computes them whole)
+        if flags & cabi.POST_V:
+            self.sqnorm_v()
+        if flags & cabi.POST_ALPHA:
+            self.cg_alpha(c1, c2, eps)
+
+    def resid_cg_step(self, c1, c2, eps, deferred):
+        self.resid_update(self.u, self.v, c1, c2, -1.0, cabi.S_ALPHA, True)
+        self.cg_beta(eps, deferred)
+
+    def adam_prep(self, cmos, cmask, spc, smask, A, B, m1a, m1b, w1, w2, lerp_weight):
+        A.copy_(self.diff_scale(cmos, self.u, cmask, -2.0 * w1))
+        B.copy_(self.diff_scale(spc, self.v, smask, -2.0 * w2))
+        if m1a is not None:
+            self.lerp(m1a, A, lerp_weight)
+            self.lerp(m1b, B, lerp_weight)
+        self.sqdiff(cmos, self.u, cmask, w1, cabi.S_LOSS1)
+        self.sqdiff(spc, self.v, smask, w2, cabi.S_LOSS2)
+
+    def sweep(self, mode, x, r=None, p=None, slices=1, after_slice=None, factored=False, fold=True):
         if factored:
             assert r is None
             r = self._resid5()
@@ -96,7 +116,7 @@ class CpuStandIn:
     def lerp(self, m, g, weight):
         m.lerp_(g.reshape(m.shape), weight)
 
-    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, m1a=None, m1b=None):
+    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, m1a=None, m1b=None, fold=True):
         n_z, X, Y = self.shape[2:]
 
         def expand(a, b):
@@ -192,4 +212,5 @@ class CpuStandIn:
         s[cabi.S_TOL] = abs(al) * math.sqrt(pp) / math.sqrt(xxn) if xxn > 0 else float("nan")
         s[cabi.S_BETA] = rs / (float(s[cabi.S_RSOLD]) + eps)
         s[cabi.S_RSOLD] = rs
+        s[cabi.S_ALPHA_LAST] = al
         s[cabi.S_ITER] += 1.0

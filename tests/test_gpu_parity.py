@@ -576,3 +576,98 @@ def test_iterate_with_a_history_array_needs_the_textbook_schedule():
     ref = np.array([[t["spatial_loss"], t["spectro_temporal_loss"], t["spatial_loss"] + t["spectro_temporal_loss"],
                      t["rsnew"]] for t in pb.trace])
     assert np.allclose(h, ref, rtol=1e-3, atol=1e-13)
+
+
+@pytest.mark.parametrize("dims", [(40, 8, 12, 64, 64, 4), (5, 3, 7, 64, 128, 4), (7, 3, 5, 6, 132, 2), (2, 2, 2, 9, 15, 3),
+                                  (3, 2, 3, 8, 8, 8), (70, 3, 5, 8, 64, 4)])
+def test_fused_small_space_launches_equal_the_stand_alone_entry_points(dims):
+    """dfx_post_sweep (u, v, UU, VV, PP/XX/XP, alpha in two launches), dfx_resid_cg_step (residual update + RR + beta in
+    three) and dfx_adam_prep (A, B, lerp, losses in two) against the entry points they replace: arrays bit for bit, the
+    scalars to the last digits (their partials are summed over a different grid)."""
+    from datafusion_amd import _cabi as cabi
+    from datafusion_amd.kernels import HipKernels
+    torch.manual_seed(4)
+    n_t, n_l, n_z, X, Y, r = dims
+    ka = HipKernels(n_t, n_l, n_z, X, Y, r, DEV, 0, 0, 4)      # steps = 4: several u_part rows and chunks
+    kb = HipKernels(n_t, n_l, n_z, X, Y, r, DEV, 0, 0, 4)
+    x, rr, p = (torch.randn(ka.shape, device=DEV) for _ in range(3))
+    c1, c2, eps = 0.013, 0.37, 1e-10
+
+    def close(a, b, rtol=1e-12):
+        assert torch.allclose(a, b, rtol=rtol, atol=0), (a, b)
+
+    for k in (ka, kb):
+        k.scal[cabi.S_ALPHA], k.scal[cabi.S_BETA], k.scal[cabi.S_RSOLD] = 0.3, 0.7, 2.5
+    for mode in (cabi.SWEEP_XP, cabi.SWEEP_PINIT, cabi.SWEEP_PROJECT):
+        for slices in (1, 3):
+            xa, pa, xb, pb = x.clone(), p.clone(), x.clone(), p.clone()
+            for k in (ka, kb):
+                k.scal[cabi.S_ALPHA] = 0.3
+            ka.sweep(mode, xa, rr, pa, slices=slices)          # fold + reduce_u + reduce_v launches
+            ka.sqnorm_v()
+            ka.cg_alpha(c1, c2, eps)
+            kb.sweep(mode, xb, rr, pb, slices=slices, fold=False)
+            kb.post_sweep(cabi.POST_U | cabi.POST_V | cabi.POST_FOLD_SWEEP | cabi.POST_ALPHA, c1, c2, eps)
+            assert torch.equal(xa, xb) and torch.equal(pa, pb)
+            assert torch.equal(ka.u, kb.u) and torch.equal(ka.v, kb.v)
+            sl = [cabi.S_PP, cabi.S_XX, cabi.S_XP]
+            assert torch.equal(ka.scal[sl], kb.scal[sl])
+            close(ka.scal[[cabi.S_UU, cabi.S_VV]], kb.scal[[cabi.S_UU, cabi.S_VV]])
+            close(ka.scal[[cabi.S_PAP, cabi.S_ALPHA]], kb.scal[[cabi.S_PAP, cabi.S_ALPHA]], rtol=1e-6)   # fp32 scalars
+    # the sharded order: u + folds first, ||v||^2 + alpha once v is complete
+    kb.scal[cabi.S_UU], kb.scal[cabi.S_VV], kb.scal[cabi.S_ALPHA] = 0.0, 0.0, 0.0
+    kb.sweep(cabi.SWEEP_PROJECT, x, fold=False, after_slice=lambda rows: None)
+    kb.post_sweep(cabi.POST_U | cabi.POST_FOLD_SWEEP)
+    assert float(kb.scal[cabi.S_VV]) == 0.0 and float(kb.scal[cabi.S_UU]) > 0
+    kb.post_sweep(cabi.POST_V | cabi.POST_V_SUMMED | cabi.POST_ALPHA, c1, c2, eps)
+    close(ka.scal[[cabi.S_UU, cabi.S_VV]], kb.scal[[cabi.S_UU, cabi.S_VV]])
+    close(ka.scal[[cabi.S_ALPHA]], kb.scal[[cabi.S_ALPHA]], rtol=1e-6)
+    # residual update + RR + beta
+    A = torch.randn(n_z, X, Y, device=DEV)
+    B = torch.randn(n_t, n_l, X // r, Y // r, device=DEV)
+    for k in (ka, kb):
+        k.new_factored_residual()
+        k.resid_update(A, B, 0.7, -1.3, 2.0, None, False)
+        k.cg_start()
+        k.scal[cabi.S_ALPHA] = 0.21
+        k.scal[cabi.S_XXNEW], k.scal[cabi.S_XX], k.scal[cabi.S_XP], k.scal[cabi.S_PP] = 7.0, 6.0, 0.4, 3.0
+    for deferred in (True, False):
+        ka.resid_update(ka.u, ka.v, c1, c2, -1.0, cabi.S_ALPHA, True)
+        ka.cg_beta(eps, deferred)
+        kb.resid_cg_step(c1, c2, eps, deferred)
+        assert torch.equal(ka.ra, kb.ra) and torch.equal(ka.rb, kb.rb)
+        sl = [cabi.S_RR, cabi.S_RA2, cabi.S_RB2, cabi.S_RAB, cabi.S_RSNEW, cabi.S_RSOLD, cabi.S_BETA, cabi.S_ITER,
+              cabi.S_ALPHA_LAST, cabi.S_NONFINITE]
+        assert torch.equal(ka.scal[sl], kb.scal[sl])
+        assert torch.equal(ka.scal[[cabi.S_TOL]], kb.scal[[cabi.S_TOL]]) and float(kb.scal[cabi.S_TOL]) > 0
+        assert float(kb.scal[cabi.S_ALPHA_LAST]) == 0.21
+    # Adam: small-space preparation
+    cmos, spc = torch.rand_like(A), torch.rand_like(B)
+    cmask = (torch.rand_like(A) > 0.3).float()
+    smask = (torch.rand(X // r, Y // r, device=DEV) > 0.3).float()
+    for cm, sm, fact in ((None, None, True), (cmask, smask, True), (cmask, smask, False)):
+        m1a, m1b = torch.randn_like(A) * 0.1, torch.randn_like(B) * 0.1
+        Ar = ka.diff_scale(cmos, ka.u, cm, -2.0 * 0.4)
+        Br = ka.diff_scale(spc, ka.v, sm, -2.0 * 0.6)
+        m1a_r, m1b_r = m1a.clone(), m1b.clone()
+        ka.lerp(m1a_r, Ar, 0.1)
+        ka.lerp(m1b_r, Br, 0.1)
+        ka.sqdiff(cmos, ka.u, cm, 0.4, cabi.S_LOSS1)
+        ka.sqdiff(spc, ka.v, sm, 0.6, cabi.S_LOSS2)
+        An, Bn = torch.empty_like(A), torch.empty_like(B)
+        kb.adam_prep(cmos, cm, spc, sm, An, Bn, m1a if fact else None, m1b if fact else None, 0.4, 0.6, 0.1)
+        assert torch.equal(Ar, An) and torch.equal(Br, Bn)
+        if fact:
+            assert torch.equal(m1a, m1a_r) and torch.equal(m1b, m1b_r)
+        sl = [cabi.S_LOSS1, cabi.S_LOSS2]
+        close(ka.scal[sl], kb.scal[sl])
+    # fused Adam step with its scalars folded by post_sweep
+    m2 = torch.rand_like(x) * 0.01
+    xa, m2a, xb, m2b = x.clone(), m2.clone(), x.clone(), m2.clone()
+    m1a, m1b = torch.randn_like(A) * 0.1, torch.randn_like(B) * 0.1
+    ka.adam_step(xa, None, m2a, A, B, cmask, 1e-2, 0.9, 0.999, 1e-8, 3, True, m1a=m1a, m1b=m1b)
+    kb.adam_step(xb, None, m2b, A, B, cmask, 1e-2, 0.9, 0.999, 1e-8, 3, True, m1a=m1a, m1b=m1b, fold=False)
+    kb.post_sweep(cabi.POST_U | cabi.POST_V | cabi.POST_FOLD_ADAM)
+    assert torch.equal(xa, xb) and torch.equal(m2a, m2b) and torch.equal(ka.u, kb.u) and torch.equal(ka.v, kb.v)
+    sl = [cabi.S_ADAM_DD, cabi.S_ADAM_XX]
+    assert torch.equal(ka.scal[sl], kb.scal[sl])

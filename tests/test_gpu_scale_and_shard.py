@@ -97,7 +97,7 @@ def test_config3_config4_per_gpu_slabs_2p32_elements_vs_collapsed_fp64(name, res
         _collapsed_cache[name] = O.collapsed_cg(f.spc.cpu(), f.cmos.cpu(), u0, v0, f.x_shape, 4, 0.5, 0.5, 10)
     a, g, alphas, rs = _collapsed_cache[name]
     err = _gpu_rel_l2_vs_collapsed(x, x0, a, g, 4)
-    rs_gpu, al_gpu = float(f.k.scal[1]), float(f.k.scal[3])
+    rs_gpu, al_gpu = float(f.k.scal[1]), float(f.k.scal[24])      # RSNEW, ALPHA_LAST
     print(f"{name} {residual}: N = 2^32, 10 iterations: rel-L2 vs fp64 collapsed CG = {err:.3e}; rsnew gpu {rs_gpu:.9e} "
           f"fp64 {rs[-1]:.9e}; alpha gpu {al_gpu:.7e} fp64 {alphas[-1]:.7e}")
     assert err <= 5e-6, err                     # bar 1e-4 (north_star); measured ~1e-7

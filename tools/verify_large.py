@@ -59,7 +59,7 @@ def main():
     out = {"shape": [n_t, n_l, n_z, xy, xy], "n_elements": f.k.N, "iterations": a.iters, "residual": a.residual,
            "inputs": "cells-like" if a.cells else "uniform",
            "rel_l2_vs_fp64_collapsed": err, "rsnew_gpu": rs_gpu, "rsnew_fp64": rs[-1], "alpha_last_fp64": alphas[-1],
-           "alpha_last_gpu": float(f.k.scal[3])}
+           "alpha_last_gpu": float(f.k.scal[24])}
     print(json.dumps(out), flush=True)
     assert err <= 1e-4
 
