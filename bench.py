@@ -148,6 +148,35 @@ def bench_adam(a, world, rank, dev, group, use_dist):
         dist.destroy_process_group()
 
 
+def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
+    """N > 1 only, same invocation as the weak-scaled headline: BASELINE.json configs[2] (t512 x l32 x z32 x 256 x 256,
+    2^35 elements, 128 GiB per vector - more than one GPU holds with the reference's three vectors) STRONG-scaled:
+    32 / N planes per rank, total work fixed.  The one-GPU anchor is measured here too: rank 0 alone runs the whole
+    volume on its GPU (it fits with the factored residual: x + p = 256 GiB) while the other ranks wait."""
+    n_t, n_l, n_z, xy, r = WORKLOADS["c3"]
+    if n_z % world:
+        return {"skipped": f"{n_z} z-planes do not split evenly over {world} ranks"}
+    steps, warmup = min(a.steps, 20), min(a.warmup, 3)
+    spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
+    res = run(a.residual, spc=spc, cmos=cmos, grp=group, steps=steps, warmup=warmup)
+    anchor = None
+    if rank == 0 and torch.cuda.mem_get_info()[0] >= 270 * 2 ** 30:
+        one = run("factored", spc=spc, cmos=cmos, grp=None, steps=min(steps, 10), warmup=2)
+        anchor = {"iters_per_s": one["its"], "ms_per_step": one["dt"] / one["steps"] * 1e3, "sweep_ms": one["sweep_ms"],
+                  "roofline_frac": one["sweep_bytes"] / (one["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                  "note": "the whole volume on rank 0's GPU alone, factored residual, measured in this invocation"}
+    dist.barrier()
+    its = res["its"]
+    out = {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r} (BASELINE configs[2]), {n_z // world} "
+                       f"z-planes per GPU", "scaling": "strong", "n_gpus": world, "n_elements": res["n_local"] * world,
+           "iters_per_s": its, "ms_per_step": res["dt"] / res["steps"] * 1e3, "steps": res["steps"],
+           "hbm_moved_GBps_per_gpu": 4.0 * res["iter_words"] * res["n_local"] * its / 1e9,
+           "kernel_ms": res["kern"], "roofline": roofline(res, a.residual, (None, "none: not profiled"), r=r),
+           "comm": res.get("comm"), "one_gpu_anchor": anchor,
+           "strong_scaling_efficiency": (its / (world * anchor["iters_per_s"])) if anchor else None}
+    return out
+
+
 def emit(obj):
     """The ONE JSON line goes to the process's original stdout; everything else any library prints on fd 1
     (RCCL prints a version banner there at communicator creation) was diverted to stderr in main()."""
@@ -204,58 +233,72 @@ def main():
     n_z = nz_gpu * world
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def run(residual):
-        """Construct, warm up, time exactly a.steps iterations of one residual mode; max over ranks."""
+    def run(residual, spc=spc, cmos=cmos, grp=group, steps=a.steps, warmup=a.warmup):
+        """Construct, warm up, time exactly `steps` iterations of one residual mode; max over ranks."""
+        sharded = grp is not None
         f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
-                     mask_noise=False, total_energy=1, device=dev, seed=42, group=group, defer_x=not a.no_defer,
+                     mask_noise=False, total_energy=1, device=dev, seed=42, group=grp, defer_x=not a.no_defer,
                      target_blocks=a.target_blocks, residual=residual, comm_slices=a.comm_slices if a.comm_slices == "auto" else int(a.comm_slices))
         fact = residual == "factored"
         sweep_name = ("sweep2" if a.no_defer else "sweep1") + ("f" if fact else "")
+
+        def fence_():
+            torch.cuda.synchronize()
+            if sharded:
+                dist.barrier()
+            torch.cuda.synchronize()
+
         f.start()
-        f.iterate(a.warmup)
+        f.iterate(warmup)
         # the timed region: HIP events bracket the dominant kernel only (roofline.achieved comes from them) ...
         f.k.timing, f.k.timing_names = {}, {sweep_name}
-        fence()
+        fence_()
         t0 = time.perf_counter()
-        f.iterate(a.steps)
-        fence()
+        f.iterate(steps)
+        fence_()
         dt = time.perf_counter() - t0
         timing = f.k.timing
-        # ... the other entry points are timed in a second, untimed loop (kernel_ms is a breakdown, not the metric)
+        # ... the other entry points, and the waits for collectives, are timed in a second, untimed loop (kernel_ms and
+        # comm are breakdowns, not the metric)
         f.k.timing, f.k.timing_names = {}, None
-        f.iterate(a.steps)
+        f.comm_timing = {} if sharded else None
+        f.iterate(steps)
         torch.cuda.synchronize()
         detail, f.k.timing = f.k.timing, None
         for name, evs in detail.items():
             timing.setdefault(name, evs)
         f.finish()  # raises if the residual ever went non-finite
-        if use_dist:
+        if sharded:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
         # per-iteration time of each entry point from the HIP events recorded on the launch stream inside the
         # timed region (a z-sharded sweep is cut into several launches: sum them)
-        kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / a.steps for name, evs in timing.items()}
+        kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps for name, evs in timing.items()}
         # words the sweep must move (DESIGN.md): x, p read + written (deferred x update) or p read + written, plus
         # the read of r when it is an explicit 5-D vector
         sweep_words = (2 if a.no_defer else 4) + (0 if fact else 1)
-        res = {"dt": dt, "its": a.steps / dt, "kern": kern, "sweep_ms": kern[sweep_name],
+        res = {"dt": dt, "its": steps / dt, "steps": steps, "kern": kern, "sweep_ms": kern[sweep_name],
                "sweep_bytes": sweep_words * 4 * f.k.N,
                "iter_words": sweep_words + (3 if a.no_defer else 0) + (0 if fact else 2),   # + dfx_axpy, + dfx_bcast
-               "launches": len(timing[sweep_name]) // a.steps, "zc": f.k.plan.zc, "n_local": f.k.N,
+               "launches": len(timing[sweep_name]) // steps, "zc": f.k.plan.zc, "n_local": f.k.N,
                "pair_probe": getattr(f.k, "pair_probe", None),
                "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "cpb", "n_blocks")}}
+        if sharded:
+            # what the compute stream spent waiting for collectives, per iteration (this rank): the all-reduce of the
+            # last band of v that the sweep did not hide, the 4-double and the 1-double all-reduces
+            waits = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps for name, evs in f.comm_timing.items()}
+            res["comm"] = {"world_size": dist.get_world_size(grp), "backend": dist.get_backend(grp),
+                           "rccl_version": ".".join(map(str, torch.cuda.nccl.version())),
+                           "v_allreduce_bytes": 4 * f.k.v.numel(), "sweep_slices": f.comm_slices,
+                           "allreduce_probe": f.comm_probe, "exposed_wait_ms_per_iteration": waits,
+                           "exposed_wait_ms_total": sum(waits.values()),
+                           "collectives_per_iteration": "v in %d band(s) + 4 doubles (UU, PP, XX, XP) + 1 double (RR)" % f.comm_slices}
         del f
         torch.cuda.empty_cache()
         return res
 
-    def roofline(res, residual, traffic):
+    def roofline(res, residual, traffic, r=r):
         ach = res["sweep_bytes"] / (res["sweep_ms"] * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": f"k_sweep_fast<{'P' if a.no_defer else 'XP'},{res['zc']},r{r},{residual}>",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
@@ -292,6 +335,9 @@ def main():
     n_vec = 3 if other == "explicit" else 2
     fits = n_vec * 4 * main_res["n_local"] < 0.93 * torch.cuda.mem_get_info()[1]
     other_res = None if (a.single or not fits) else run(other)
+    # DFX_BENCH_STRONG=1 (with DFX_FORCE_COMM=1): rehearse the strong-scaling leg with one rank on a 1-GPU box
+    want_strong = group is not None and a.workload == "c2" and (world > 1 or os.environ.get("DFX_BENCH_STRONG") == "1")
+    strong = strong_scaling_leg(a, world, rank, dev, group, run, roofline) if want_strong else None
     n_local = main_res["n_local"]
     n_total = n_local * world
     its, dt = main_res["its"], main_res["dt"]
@@ -328,6 +374,10 @@ def main():
             "words_moved_per_iteration": f"{o['iter_words']} N",
             "hbm_moved_GBps": 4.0 * o["iter_words"] * n_total * o["its"] / 1e9, "kernel_ms": o["kern"],
             "roofline": roofline(o, other, pmc_traffic(other, o["zc"]))}
+    if "comm" in main_res:
+        out["comm"] = main_res["comm"]
+    if strong is not None:
+        out["config3_strong_scaling"] = strong
     if rank == 0:
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_t, n_l, n_z, xy, r)

@@ -38,6 +38,28 @@ class ShardComm:
         # lets a single-GPU box exercise the real RCCL call path
         self._always = self.group is not None and os.environ.get("DFX_FORCE_COMM") == "1"
 
+    def measure_allreduce(self, t: torch.Tensor, reps: int = 2):
+        """Wall time (s) of one sum-all-reduce of `t` and of an 8-element one, as this group delivers them right now:
+        max over ranks (every rank must reach the same slicing decision from it).  `t`'s contents are summed in place
+        (pass scratch).  Used once per solve by FusionCG to size the overlap of the v all-reduce."""
+        import time
+        small = torch.zeros(8, dtype=t.dtype, device=t.device)
+        out = []
+        for buf in (t, small):
+            self.sum_(buf)                                   # warm: communicator set-up, first-touch
+            if buf.device.type == "cuda":
+                torch.cuda.synchronize(buf.device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.sum_(buf)
+            if buf.device.type == "cuda":
+                torch.cuda.synchronize(buf.device)
+            out.append((time.perf_counter() - t0) / reps)
+        m = torch.tensor(out, dtype=torch.float64, device=t.device if not self._stage else "cpu")
+        if self.size > 1:
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        return float(m[0]), float(m[1])
+
     def sum_async(self, t: torch.Tensor):
         """Start a sum-all-reduce of `t` ordered after the work already queued on the current stream; returns a
         handle for wait() (None when nothing is pending: one shard, or a host-staged gloo group)."""

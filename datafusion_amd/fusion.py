@@ -266,22 +266,49 @@ class FusionCG(Fusion):
         self.w1 = self.weights["spatial"]
         self.w2 = self.weights["spectro_temporal"]
         self._r = self._p = None
-        self.comm_slices = self._auto_slices() if comm_slices == "auto" else int(comm_slices)
+        # "auto": decided in start() from one timed all-reduce of v; a number: that many launches (1 = one all-reduce
+        # after the whole sweep, no overlap - the setting to rule the asynchronous path out with)
+        self._comm_slices_arg = comm_slices if comm_slices == "auto" else int(comm_slices)
+        self.comm_slices = 1 if comm_slices == "auto" else int(comm_slices)
+        self.comm_probe = None
+        self.comm_timing = None   # bench.py: dict name -> list of (start, end) events around the waits for collectives
         self._pending_x = False
         self._stopped = False
+
+    SLICE_LAUNCH_COST_S = 50e-6   # measured, one-rank RCCL group at C2: 2.81 / 2.86 / 2.96 / 3.15 ms per iteration
+                                  # for 1 / 2 / 4 / 8 launches (kernel tail + relaunch, the band's dfx_reduce_v, hand-over)
 
     def _auto_slices(self) -> int:
         """How many launches to cut a sharded sweep into.  Every band's all-reduce but the last hides behind the
         bands still being swept; bands shrink linearly (HipKernels._slice_bounds), so with k launches the exposed
-        one carries 2/(k(k+1)) of v.  Each extra launch costs ~50 us on an MI355X (measured with a one-rank RCCL
-        group at C2: 2.81 / 2.86 / 2.96 / 3.15 ms per iteration for k = 1 / 2 / 4 / 8); the all-reduce is priced at
-        an assumed 70 GB/s + 30 us over xGMI.  C2-sized shards (16 MiB of v) get k = 2, the 256 MiB of configs 3 / 4
-        k = 6."""
+        one carries 2/(k(k+1)) of v.  Each extra launch costs ~50 us on an MI355X.  The all-reduce is priced from a
+        MEASUREMENT on this group, taken here: one all-reduce of the v buffer and one of 8 floats (latency), max over
+        ranks -> T(bytes) = lat + bytes / bw.  Every rank computes the same k from the same two numbers."""
         if self.comm.size <= 1 and not self.comm._always:
             return 1
-        t_ar = 4.0 * self.n_times * self.n_lambdas * self.spc.shape[-2] * self.spc.shape[-1] / 70e9 + 30e-6
-        cost = {k: t_ar * 2.0 / (k * (k + 1)) + 50e-6 * (k - 1) for k in range(1, cabi.MAX_SLICES + 1)}
-        return min(cost, key=cost.get)
+        t_full, t_lat = self.comm.measure_allreduce(self.k.v)
+        nbytes = 4.0 * self.k.v.numel()
+        bw = nbytes / max(t_full - t_lat, 1e-7)
+        cost = {k: t_lat + nbytes * 2.0 / (k * (k + 1)) / bw + self.SLICE_LAUNCH_COST_S * (k - 1)
+                for k in range(1, cabi.MAX_SLICES + 1)}
+        best = min(cost, key=cost.get)
+        self.comm_probe = {"v_bytes": int(nbytes), "allreduce_v_s": t_full, "allreduce_8_floats_s": t_lat,
+                           "busbw_GBps": nbytes / max(t_full - t_lat, 1e-7) / 1e9, "slices": best,
+                           "modelled_exposed_s": cost[best]}
+        return best
+
+    def _comm_timed(self, name, fn):
+        """Run `fn` (which makes the compute stream wait for collectives); when comm_timing is set, bracket it with
+        events on the compute stream: their distance is the time the stream stood still, i.e. exposed communication."""
+        if self.comm_timing is None:
+            return fn()
+        st = torch.cuda.current_stream(self.k.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        out = fn()
+        e1.record(st)
+        self.comm_timing.setdefault(name, []).append((e0, e1))
+        return out
 
     def _save_solver_state(self):
         """loss() / marginals() project x into k.u, k.v and overwrite UU, PP, XX, XP - which, between two iterate()
@@ -318,8 +345,8 @@ class FusionCG(Fusion):
             k.sweep(mode, self.x, self._r, self._p, slices=self.comm_slices,
                     after_slice=lambda rows: pending.append(c.sum_async(rows)), factored=fact, fold=False)
             k.post_sweep(cabi.POST_U | cabi.POST_FOLD_SWEEP)
-            c.wait(pending)
-            c.sum_(k.scal[cabi.S_UU:cabi.S_XP + 1])       # UU, PP, XX, XP partials
+            self._comm_timed("wait_v", lambda: c.wait(pending))
+            self._comm_timed("scalars4", lambda: c.sum_(k.scal[cabi.S_UU:cabi.S_XP + 1]))   # UU, PP, XX, XP partials
             k.post_sweep(cabi.POST_V | cabi.POST_V_SUMMED | al, c1, c2, e)    # VV identical on every rank
         else:
             k.sweep(mode, self.x, self._r, self._p, factored=fact, fold=False)
@@ -366,6 +393,8 @@ class FusionCG(Fusion):
         k, c = self.k, self.comm
         c1, c2 = self._coefs()
         fact = self.residual == "factored"
+        if self._comm_slices_arg == "auto" and self.comm_probe is None and (c.size > 1 or c._always):
+            self.comm_slices = self._auto_slices()          # k.v is scratch here: it is overwritten by the projection below
         if self._p is None:
             self._p = k.new_vector_paired(self.x, self._placement_tries(planned_iterations))
             if fact:
@@ -419,7 +448,7 @@ class FusionCG(Fusion):
                     k.resid_update(k.u, k.v, c1, c2, -1.0, cabi.S_ALPHA, True)
                 else:
                     k.bcast(rv, rv, k.u, k.v, None, c1, c2, -1.0, cabi.S_ALPHA)
-                c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1])
+                self._comm_timed("scalar_rr", lambda: c.sum_(k.scal[cabi.S_RR:cabi.S_RR + 1]))
                 k.cg_beta(eps, deferred)                                        # rsnew, tol, beta
             if self.tol is not None or self.verbose or history is not None:
                 s = k.scal.cpu()                                                # one sync, as fusion.py:448

@@ -25,8 +25,17 @@ def _worker(rank, world, port, case, q):
     kw = dict(weights=w, init_type=case["init"], tol=case["tol"], mask_noise=case["mask"], device="cpu",
               group=dist.group.WORLD, defer_x=case["defer"])
     if case["method"] == "cg":
-        f = FusionCG(spc, cmos, residual=case.get("residual", "factored"), **kw)
+        f = FusionCG(spc, cmos, residual=case.get("residual", "factored"), comm_slices=case.get("slices", "auto"), **kw)
         x, _, _ = f(case["iters"], return_numpy=False)
+        if case.get("slices", "auto") == "auto":
+            # the slicing of the sharded sweep comes from one all-reduce timed on this group, and every rank must
+            # have drawn the same number from it (the bands are collectives: their sizes have to match)
+            assert f.comm_probe is not None and f.comm_probe["v_bytes"] == 4 * f.k.v.numel()
+            ks = [None] * world
+            dist.all_gather_object(ks, f.comm_slices)
+            assert len(set(ks)) == 1 and 1 <= ks[0] <= 16
+        else:
+            assert f.comm_probe is None and f.comm_slices == case["slices"]
     else:
         f = FusionAdam(spc, cmos, fused=case.get("fused", True), moment1=case.get("moment1", "factored"), **kw)
         x, _, _ = f(lr=1e-7, max_iterations=case["iters"], return_numpy=False)
@@ -100,3 +109,10 @@ def test_gloo_adam_fused_explicit_first_moment():
 
 def test_gloo_adam_autograd():
     _check(dict(method="adam", init="baseline", tol=1e-12, mask=False, defer=True, iters=4, fused=False), 29614)
+
+
+def test_gloo_cg_fixed_slicing_three_bands_and_one_band():
+    """comm_slices given as a number: no probe; 1 = a single all-reduce after the whole sweep (the setting that rules
+    the overlapped path out), 3 = three bands."""
+    _check(dict(method="cg", init="baseline", tol=None, mask=False, defer=True, iters=6, slices=3), 29618)
+    _check(dict(method="cg", init="baseline", tol=None, mask=False, defer=True, iters=6, slices=1), 29619)

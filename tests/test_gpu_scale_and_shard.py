@@ -252,6 +252,11 @@ def test_z_sharded_hip_path_three_ranks_on_one_gpu():
     assert np.allclose([l1, l2], [float(m1), float(m2)], rtol=1e-3, atol=1e-16)
 
 
+def _bit_checksum(x):
+    """Exact checksum of a float32 tensor's bit patterns (int64 sum of the int32 views), one time bin at a time."""
+    return int(sum(int(x[t].view(torch.int32).sum(dtype=torch.int64)) for t in range(x.shape[0])))
+
+
 def _rccl_worker(port, q):
     sys.path[:0] = [ROOT]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DFX_FORCE_COMM="1")
@@ -263,9 +268,21 @@ def _rccl_worker(port, q):
     f = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=3e-3, device=DEV, group=dist.group.WORLD)
     assert f.comm._always and f.comm.group is not None
     x, _, _ = f(10)
+    it = f.curr_iter
     g = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, group=dist.group.WORLD)
     xa, _, _ = g(lr=1e-7, max_iterations=3)
-    q.put((x, f.curr_iter, xa))
+    probe = f.comm_probe                     # comm_slices="auto": one timed all-reduce of v decided the slicing
+    del f, g
+    torch.cuda.empty_cache()
+    # config 3's per-GPU slab at G = 8: its 256 MiB v all-reduced in 6 bands while the sweep goes on
+    big = None
+    if torch.cuda.mem_get_info()[0] > 40 * (1 << 30):
+        spc, cmos = Or.synthetic_inputs(*SLABS_2P32["c3g8"])
+        h = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, group=dist.group.WORLD,
+                     comm_slices=6)
+        xb, _, _ = h(5, return_numpy=False)
+        big = (_bit_checksum(xb), h.k.v.numel() * 4, h.comm_slices)
+    q.put((x, it, xa, probe, big))
     dist.destroy_process_group()
 
 
@@ -275,9 +292,20 @@ def test_collectives_through_real_rccl_one_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(29641, q))
     p.start()
-    x, it, xa = q.get(timeout=150)
+    x, it, xa, probe, big = q.get(timeout=200)
     p.join(60)
     assert p.exitcode == 0
+    assert probe is not None and 1 <= probe["slices"] <= 16 and probe["allreduce_v_s"] > 0, probe
+    print("one-rank RCCL all-reduce probe:", probe)
+    if big is not None:
+        from datafusion_amd import FusionCG
+        assert big[1] == 256 << 20 and big[2] == 6
+        spc, cmos = O.synthetic_inputs(*SLABS_2P32["c3g8"])
+        f = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV)
+        xs, _, _ = f(5, return_numpy=False)
+        assert _bit_checksum(xs) == big[0]        # slicing + a one-rank all-reduce change nothing, bit for bit
+        del xs, f
+        torch.cuda.empty_cache()
     spc, cmos = O.synthetic_inputs(6, 4, 8, 64, 4, seed=6)
     pb = O.prepare(spc, cmos, weights=W, init_type="baseline", tol=3e-3)
     xo = O.cg(pb, 10, with_loss=False)
