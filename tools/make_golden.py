@@ -72,9 +72,75 @@ def case_cg(name, spc, cmos, iters_list, weights=W, check=1e-6, **kw):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def scrape_history():
+    """The reference keeps `history` local to __call__; with verbose=True it draws one scatter plot per column."""
+    import matplotlib.pyplot as plt
+    fig = plt.gcf()
+    cols = [ax.collections[0].get_offsets()[:, 1].data for ax in fig.axes]
+    plt.close("all")
+    return np.stack(cols, 1)
+
+
+def adam_cases():
+    """Adam variant: 5 steps, losses of every step and the first gradient - all taken from the REFERENCE objects:
+    grad0 is the reference's own x.grad after a one-iteration call (fusion.py:338-341: loss.backward(), then
+    _mask_gradients when mask_noise), the loss history is what its verbose run plots."""
+    for name, mk, nn, lr in (("adam_t6l4z3_32", False, False, 1e-8), ("adam_t6l4z3_32_mask_nn", True, True, 1e-7)):
+        spc, cmos = O.cells_like_inputs(6, 4, 3, 32, 4, seed=9)
+        f = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, mask_noise=mk)
+        x0 = f.x.clone().numpy()
+        l1, l2 = f.loss()
+        x, spc_n, cmos_n = f(lr=lr, max_iterations=5, non_neg=nn)
+        f1 = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, mask_noise=mk)
+        x_1, _, _ = f1(lr=lr, max_iterations=1, non_neg=nn)
+        grad0 = f1.x.grad.detach().clone().numpy()                  # the reference's gradient (masked when mask_noise)
+        fv = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, mask_noise=mk, verbose=True)
+        xv, _, _ = fv(lr=lr, max_iterations=5, non_neg=nn)
+        hist = scrape_history()                                      # (5, 3): spatial, spectro-temporal, total
+        assert np.array_equal(xv, x) and hist.shape == (5, 3)
+        pb = O.prepare(spc, cmos, weights=W, init_type="baseline", tol=None, mask_noise=mk)
+        xo = O.adam(pb, lr, 5, non_neg=nn)
+        e = O.rel_l2(xo, x)
+        g_or = pb.trace[0]["grad"].numpy()
+        if mk:
+            g_or = g_or * pb.cmos_mask.numpy()[None, None]
+        eg = O.rel_l2(g_or, grad0)
+        print(f"{name}: oracle-vs-reference rel_l2 x={e:.3e} grad0={eg:.3e}")
+        assert e <= 1e-6 and eg <= 1e-6
+        assert abs(pb.trace[0]["spatial_loss"] - float(l1)) <= 1e-6 * abs(float(l1))
+        lo = np.array([[t["spatial_loss"], t["spectro_temporal_loss"]] for t in pb.trace])
+        assert np.allclose(lo, hist[:, :2], rtol=1e-5)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), spc=spc, cmos=cmos, x0=x0, x_1=x_1, x_5=x, lr=lr,
+                            loss0=np.array([float(l1), float(l2)]), grad0=grad0, grad0_masked=np.array(mk),
+                            losses=hist[:, :2], w1=0.5, w2=0.5)
+
+
+def cg_verbose_tol_case():
+    """verbose=True together with a tolerance: the history rows stop where the loop breaks (fusion.py:451-478: the
+    break comes before the row of that iteration is written) and the rest stays zero."""
+    spc, cmos = uniform(8, 4, 4, 32, 4, seed=6)
+    f = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=3e-3, verbose=True)
+    x, _, _ = f(50)
+    hist = scrape_history()
+    pb = O.prepare(spc, cmos, weights=W, init_type="baseline", tol=3e-3)
+    xo = O.cg(pb, 50)
+    assert pb.curr_iter == f.curr_iter and O.rel_l2(xo, x) <= 1e-6
+    assert hist.shape == (50, 4) and np.all(hist[f.curr_iter - 1:] == 0) and np.all(hist[:f.curr_iter - 1, 3] > 0)
+    print("verbose + tol case: stop at", f.curr_iter, "rows written", f.curr_iter - 1)
+    np.savez_compressed(os.path.join(OUT, "cg_verbose_tol_t8l4z4_32.npz"), spc=spc, cmos=cmos, x=x,
+                        curr_iter=f.curr_iter, hist=hist, w1=0.5, w2=0.5)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    only = set(sys.argv[1:])
+    if only:                       # regenerate some fixtures only: python tools/make_golden.py adam cg_verbose_tol
+        if "adam" in only:
+            adam_cases()
+        if "cg_verbose_tol" in only:
+            cg_verbose_tol_case()
+        return
 
     # --- CG, uniform inputs, several shapes incl. non power of two and r in {2,4,8}
     case_cg("cg_t8l4z4_32_r4", *uniform(8, 4, 4, 32, 4), [1, 5, 20])
@@ -126,23 +192,8 @@ def main():
     assert O.rel_l2(xo, xb) <= 1e-7
     np.savez_compressed(os.path.join(OUT, "baseline_t5l3z4_24.npz"), spc=spc, cmos=cmos, x=xb)
 
-    # --- Adam variant: 5 steps, losses, first gradient; plain, masked + non_neg
-    for name, mk, nn, lr in (("adam_t6l4z3_32", False, False, 1e-8), ("adam_t6l4z3_32_mask_nn", True, True, 1e-7)):
-        spc, cmos = O.cells_like_inputs(6, 4, 3, 32, 4, seed=9)
-        f = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, mask_noise=mk)
-        x0 = f.x.clone().numpy()
-        l1, l2 = f.loss()
-        x, spc_n, cmos_n = f(lr=lr, max_iterations=5, non_neg=nn)
-        pb = O.prepare(spc, cmos, weights=W, init_type="baseline", tol=None, mask_noise=mk)
-        xo = O.adam(pb, lr, 5, non_neg=nn)
-        e = O.rel_l2(xo, x)
-        print(f"{name}: oracle-vs-reference rel_l2={e:.3e}")
-        assert e <= 1e-6
-        assert abs(pb.trace[0]["spatial_loss"] - float(l1)) <= 1e-6 * abs(float(l1))
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), spc=spc, cmos=cmos, x0=x0, x_5=x, lr=lr,
-                            loss0=np.array([float(l1), float(l2)]), grad0=pb.trace[0]["grad"].numpy(),
-                            losses=np.array([[t["spatial_loss"], t["spectro_temporal_loss"]] for t in pb.trace]),
-                            w1=0.5, w2=0.5)
+    adam_cases()
+    cg_verbose_tol_case()
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))}
     print(sizes, sum(sizes.values()))
 
