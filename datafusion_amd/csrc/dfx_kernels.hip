@@ -142,6 +142,31 @@ __device__ __forceinline__ void block_store3(double a, double b, double c, doubl
     }
 }
 
+// out[k] = sum over rows [0, n_rows) of column k (k < NC <= 3) of a DFX_NPART-wide table, by one workgroup of 256
+// threads in ONE pass: strided per-thread sums, wave shuffles, the four wave results added in wave order.  Fixed
+// order: deterministic.  Every thread returns the sums.
+template <int NC>
+__device__ __forceinline__ void fold_cols(const double *parts, int n_rows, double (&out)[NC]) {
+    __shared__ double sh[4][NC];
+    double acc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = 0.0;
+    for (int b = threadIdx.x; b < n_rows; b += 256) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) acc[k] += parts[(long long)b * DFX_NPART + k];
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = wave_sum(acc[k]);
+    __syncthreads();                                   // sh may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) sh[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NC; ++k) out[k] = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
+}
+
 __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
 __device__ __forceinline__ f4 ld4s(const float *p) {  // streamed once
@@ -812,37 +837,13 @@ __global__ __launch_bounds__(256) void k_reduce1(const float *a, const float *b,
     block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
 }
 
-// dst[k] = scale * sum_rows parts[row*DFX_NPART + k]; one workgroup; fixed order.
+// dst[k] = scale * sum_rows parts[row*DFX_NPART + k], k < nvals <= 3; one workgroup; fixed order.
 __global__ __launch_bounds__(256) void k_fold(const double *parts, int n_rows, int nvals, double *dst,
                                               double scale) {
-    __shared__ double sh[256];
-    for (int k = 0; k < nvals; ++k) {
-        double s = 0;
-        for (int b = threadIdx.x; b < n_rows; b += 256) s += parts[(long long)b * DFX_NPART + k];
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) dst[k] = scale * sh[0];
-        __syncthreads();
-    }
-}
-
-// sum over rows [0, n_rows) of column k of a DFX_NPART-wide table, by the whole workgroup (256 threads), fixed order
-__device__ __forceinline__ double fold_col(const double *parts, int n_rows, int k, double *sh) {
-    double s = 0;
-    for (int b = threadIdx.x; b < n_rows; b += 256) s += parts[(long long)b * DFX_NPART + k];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    const double r = sh[0];
-    __syncthreads();
-    return r;
+    double r[3];
+    fold_cols<3>(parts, n_rows, r);     // rows always hold three values (block_store3): unused columns cost nothing
+    if (threadIdx.x == 0)
+        for (int k = 0; k < nvals; ++k) dst[k] = scale * r[k];
 }
 
 __device__ __forceinline__ void cg_alpha_body(double *s, double c1, double c2, double eps) {
@@ -944,30 +945,23 @@ __global__ __launch_bounds__(256) void k_post_sweep(const PostArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_post_fold(const PostArgs a) {
-    __shared__ double sh[256];
-    const int n_own = a.nbu + a.nbv;
     double *s = a.scal;
-    if (a.flags & DFX_POST_U) {
-        const double r = fold_col(a.part, n_own, 0, sh);
-        if (threadIdx.x == 0) s[DFX_S_UU] = r;
-    }
-    if (a.flags & DFX_POST_V) {
-        const double r = fold_col(a.part, n_own, 1, sh);
-        if (threadIdx.x == 0) s[DFX_S_VV] = r;
-    }
+    double own[2], rows[3];
+    fold_cols<2>(a.part, a.nbu + a.nbv, own);
+    if (a.flags & (DFX_POST_FOLD_SWEEP | DFX_POST_FOLD_ADAM)) fold_cols<3>(a.fold_rows, a.n_fold_rows, rows);
+    if (threadIdx.x != 0) return;
+    if (a.flags & DFX_POST_U) s[DFX_S_UU] = own[0];
+    if (a.flags & DFX_POST_V) s[DFX_S_VV] = own[1];
     if (a.flags & DFX_POST_FOLD_SWEEP) {
-        for (int k = 0; k < 3; ++k) {
-            const double r = fold_col(a.fold_rows, a.n_fold_rows, k, sh);
-            if (threadIdx.x == 0) s[DFX_S_PP + k] = r;       // PP, XX, XP are consecutive slots
-        }
+        s[DFX_S_PP] = rows[0];       // PP, XX, XP
+        s[DFX_S_XX] = rows[1];
+        s[DFX_S_XP] = rows[2];
     }
     if (a.flags & DFX_POST_FOLD_ADAM) {
-        for (int k = 0; k < 2; ++k) {
-            const double r = fold_col(a.fold_rows, a.n_fold_rows, k, sh);
-            if (threadIdx.x == 0) s[DFX_S_ADAM_DD + k] = r;  // ADAM_DD, ADAM_XX
-        }
+        s[DFX_S_ADAM_DD] = rows[0];
+        s[DFX_S_ADAM_XX] = rows[1];
     }
-    if ((a.flags & DFX_POST_ALPHA) && threadIdx.x == 0) cg_alpha_body(s, a.c1, a.c2, a.eps);
+    if (a.flags & DFX_POST_ALPHA) cg_alpha_body(s, a.c1, a.c2, a.eps);
 }
 
 // Everything a fused Adam iteration does in the small space BEFORE its 5-D pass, in one launch (fusion.py:332-338:
@@ -1033,11 +1027,11 @@ __global__ __launch_bounds__(256) void k_adam_prep(const PrepArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_prep_fold(const double *part, int n_rows, double w1, double w2, double *scal) {
-    __shared__ double sh[256];
-    const double s1 = fold_col(part, n_rows, 0, sh), s2 = fold_col(part, n_rows, 1, sh);
+    double r[2];
+    fold_cols<2>(part, n_rows, r);
     if (threadIdx.x == 0) {
-        scal[DFX_S_LOSS1] = w1 * s1;
-        scal[DFX_S_LOSS2] = w2 * s2;
+        scal[DFX_S_LOSS1] = w1 * r[0];
+        scal[DFX_S_LOSS2] = w2 * r[1];
     }
 }
 
@@ -1121,13 +1115,13 @@ __global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, cons
 // (k_cg_beta; beta_mode = the deferred flag).
 __global__ __launch_bounds__(256) void k_resid_rr(const double *parts, int n_rows, double m, double zr2, double *s,
                                                   int beta_mode, double eps) {
-    __shared__ double sh[256];
-    const double s0 = fold_col(parts, n_rows, 0, sh), s1 = fold_col(parts, n_rows, 1, sh), s2 = fold_col(parts, n_rows, 2, sh);
+    double r[3];
+    fold_cols<3>(parts, n_rows, r);
     if (threadIdx.x == 0) {
-        s[DFX_S_RA2] = s0;
-        s[DFX_S_RB2] = s1;
-        s[DFX_S_RAB] = s2;
-        s[DFX_S_RR] = m * s0 + 2.0 * s2 + zr2 * s1;
+        s[DFX_S_RA2] = r[0];
+        s[DFX_S_RB2] = r[1];
+        s[DFX_S_RAB] = r[2];
+        s[DFX_S_RR] = m * r[0] + 2.0 * r[2] + zr2 * r[1];
         if (beta_mode >= 0) cg_beta_body(s, eps, beta_mode);
     }
 }

@@ -620,4 +620,4 @@ class FusionAdam(Fusion):
             if tolerance is not None and tolerance < self.tol:
                 break
             if history is not None:
-                history[i] = [float(spatial_loss), float(spectro_temporal_loss), float(loss)]
+                history[i] = [spatial_loss.item(), spectro_temporal_loss.item(), loss.item()]
