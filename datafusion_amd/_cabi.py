@@ -77,6 +77,7 @@ SIGNATURES = {
     "dfx_block_sum": [_P, _P, _i64, _i64, _i64, _i32, _P],
     "dfx_block_expand": [_P, _P, _i64, _i64, _i64, _i32, _f, _P],
     "dfx_baseline_init": [_G, _P, _P, _P, _f, _P, _P, _P, _P],
+    "dfx_resize_stack": [_P, _P, _P, _P, _i64, _i64, _i64, _i64, _i64, _i32, _P],
 }
 
 _lib = None

@@ -1264,6 +1264,68 @@ __global__ __launch_bounds__(256) void k_block_expand(const float *in, float *ou
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Input stage (utils.py:411-427 load_data): skimage.transform.resize(cmos, (S1, S2, nZ)) with its defaults, restated
+// per (x, y) plane of a float64 stack: Gaussian pre-filter (scipy.ndimage.gaussian_filter: separable, truncate 4,
+// mode "reflect" = half-sample symmetric) on the axes that shrink, then order-1 interpolation at the centres of the
+// output grid (scipy.ndimage.zoom(order=1, mode="reflect", grid_mode=True)).  PARITY UNPINNED against scikit-image
+// itself (absent from the image); checked against the scipy calls it is built from.
+// ------------------------------------------------------------------------------------------
+#define DFX_RESIZE_MAXR 64
+struct GaussArgs {
+    const double *in;
+    double *out;
+    long long planes;
+    int X, Y, axis, radius;      // axis 0: along x (stride Y), 1: along y (stride 1)
+    double w[DFX_RESIZE_MAXR + 1];   // w[k], k = 0..radius (symmetric kernel, normalised)
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {   // d c b a | a b c d | d c b a
+    while (i < 0 || i >= n) i = i < 0 ? -i - 1 : 2 * n - i - 1;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void k_gauss_axis(const GaussArgs a) {
+    const long long P = (long long)a.X * a.Y, n = a.planes * P;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long pl = i / P;
+        const int xy = (int)(i - pl * P), x = xy / a.Y, y = xy - x * a.Y;
+        const double *base = a.in + pl * P;
+        const int len = a.axis == 0 ? a.X : a.Y, pos = a.axis == 0 ? x : y;
+        // scipy's correlate1d for a symmetric kernel: centre tap, then the pairs from the outermost inwards
+        double t = base[xy] * a.w[0];
+        for (int k = a.radius; k >= 1; --k) {
+            const int lo = reflect_idx(pos - k, len), hi = reflect_idx(pos + k, len);
+            const double vlo = a.axis == 0 ? base[(long long)lo * a.Y + y] : base[(long long)x * a.Y + lo];
+            const double vhi = a.axis == 0 ? base[(long long)hi * a.Y + y] : base[(long long)x * a.Y + hi];
+            t += (vlo + vhi) * a.w[k];
+        }
+        a.out[i] = t;
+    }
+}
+
+// out[pl][i][j] (or out[pl][j][i] when transpose) = bilinear sample of in[pl] at ((i + 0.5) X / S1 - 0.5, (j + 0.5) Y / S2 - 0.5)
+__global__ __launch_bounds__(256) void k_zoom_linear(const double *in, double *out, long long planes, int X, int Y,
+                                                     int S1, int S2, int transpose) {
+    const long long Po = (long long)S1 * S2, n = planes * Po;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const double fx = (double)X / (double)S1, fy = (double)Y / (double)S2;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += stride) {
+        const long long pl = o / Po;
+        const int ij = (int)(o - pl * Po), i = ij / S2, j = ij - i * S2;
+        const double cx = ((double)i + 0.5) * fx - 0.5, cy = ((double)j + 0.5) * fy - 0.5;
+        const double flx = floor(cx), fly = floor(cy);
+        const double wx = cx - flx, wy = cy - fly;
+        const int x0 = reflect_idx((int)flx, X), x1 = reflect_idx((int)flx + 1, X);
+        const int y0 = reflect_idx((int)fly, Y), y1 = reflect_idx((int)fly + 1, Y);
+        const double *b = in + pl * (long long)X * Y;
+        const double v = (1.0 - wx) * ((1.0 - wy) * b[(long long)x0 * Y + y0] + wy * b[(long long)x0 * Y + y1]) +
+                         wx * ((1.0 - wy) * b[(long long)x1 * Y + y0] + wy * b[(long long)x1 * Y + y1]);
+        out[transpose ? pl * Po + (long long)j * S1 + i : o] = v;
+    }
+}
+
 struct BaseArgs {
     const float *spc;
     const float *zw;
@@ -2018,6 +2080,49 @@ int dfx_recip(double *dst, const double *src, double num, void *stream) {
     if (!dst || !src) return fail(DFX_EINVAL, "dfx_recip: NULL");
     hipLaunchKernelGGL(k_recip, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, src, num);
     DFX_LAUNCH_CHECK("dfx_recip");
+    return 0;
+}
+
+static int gauss_pass(const double *in, double *out, int64_t planes, int X, int Y, int axis, double factor,
+                      hipStream_t st) {
+    GaussArgs a;
+    a.in = in;
+    a.out = out;
+    a.planes = planes;
+    a.X = X;
+    a.Y = Y;
+    a.axis = axis;
+    const double sigma = (factor - 1.0) / 2.0;                 // skimage: anti_aliasing_sigma = (factor - 1) / 2
+    const int radius = (int)(4.0 * sigma + 0.5);               // scipy: truncate = 4.0
+    if (radius > DFX_RESIZE_MAXR) return fail(DFX_EINVAL, "dfx_resize_stack: shrink factor too large (radius > 64)");
+    a.radius = radius;
+    double sum = 0.0;                                          // scipy _gaussian_kernel1d: exp(-0.5 x^2 / sigma^2), normalised
+    for (int k = -radius; k <= radius; ++k) sum += exp(-0.5 / (sigma * sigma) * (double)k * (double)k);
+    for (int k = 0; k <= radius; ++k) a.w[k] = exp(-0.5 / (sigma * sigma) * (double)k * (double)k) / sum;
+    hipLaunchKernelGGL(k_gauss_axis, dim3(ew_blocks(planes * X * Y, 1)), dim3(256), 0, st, a);
+    DFX_LAUNCH_CHECK("dfx_resize_stack(gauss)");
+    return 0;
+}
+
+int dfx_resize_stack(const double *in, double *tmp_a, double *tmp_b, double *out, int64_t planes, int64_t X,
+                     int64_t Y, int64_t S1, int64_t S2, int32_t transpose_out, void *stream) {
+    if (!in || !tmp_a || !tmp_b || !out || planes <= 0 || X <= 0 || Y <= 0 || S1 <= 0 || S2 <= 0 ||
+        X > 0x7fff || Y > 0x7fff || S1 > 0x7fff || S2 > 0x7fff)
+        return fail(DFX_EINVAL, "dfx_resize_stack: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const double fx = (double)X / (double)S1, fy = (double)Y / (double)S2;
+    const double *cur = in;
+    if (fx > 1.0) {            // anti-aliasing only on the axes that shrink; sigma = 0 elsewhere (no pass)
+        if (int rc = gauss_pass(cur, tmp_a, planes, (int)X, (int)Y, 0, fx, st)) return rc;
+        cur = tmp_a;
+    }
+    if (fy > 1.0) {
+        if (int rc = gauss_pass(cur, tmp_b, planes, (int)X, (int)Y, 1, fy, st)) return rc;
+        cur = tmp_b;
+    }
+    hipLaunchKernelGGL(k_zoom_linear, dim3(ew_blocks(planes * S1 * S2, 1)), dim3(256), 0, st, cur, out,
+                       (long long)planes, (int)X, (int)Y, (int)S1, (int)S2, (int)transpose_out);
+    DFX_LAUNCH_CHECK("dfx_resize_stack(zoom)");
     return 0;
 }
 

@@ -282,6 +282,16 @@ int dfx_recip(double *dst, const double *src, double num, void *stream);
 int dfx_baseline_init(const dfx_geom *g, const float *spc, const float *zw, float *x, float coef_host,
                       const double *coef_dev, double *scal, double *part, void *stream);
 
+/* Input stage, utils.py:411-427 (load_data): `skimage.transform.resize(cmos_xyz, (S1, S2, nZ))` with its defaults
+ * (order 1, mode "reflect", anti-aliasing Gaussian sigma = (factor - 1) / 2 truncated at 4 sigma on the axes that
+ * shrink), restated per plane of a float64 (planes, X, Y) stack on the device: out (planes, S1, S2), or
+ * (planes, S2, S1) when transpose_out (load_data's final np.transpose(., (2, 1, 0)) swaps x and y).
+ * tmp_a, tmp_b: workspaces of planes*X*Y doubles each.  The z axis is not resized (factor 1).
+ * scikit-image is not available to check against: PARITY UNPINNED; the tests compare with the scipy.ndimage calls
+ * skimage's resize is built from (gaussian_filter + zoom(order=1, grid_mode=True)). */
+int dfx_resize_stack(const double *in, double *tmp_a, double *tmp_b, double *out, int64_t planes, int64_t X,
+                     int64_t Y, int64_t S1, int64_t S2, int32_t transpose_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -327,8 +327,11 @@ def test_readme_flow_on_a_synthetic_acquisition(tmp_path):
     path = tmp_path / "cells_synth.npz"
     np.savez(path, spc=spc, cmos=big.numpy(), time_axis=np.linspace(0, 12.5, 12),
              spectral_axis=np.linspace(500, 700, 16))
-    spc_l, cmos_l, t_ax, l_ax = load_data(path, max_xy_size=64)
+    spc_l, cmos_l, t_ax, l_ax = load_data(path, max_xy_size=64, device=DEV)      # the resize runs on the GPU
     assert spc_l.shape == (12, 16, 16, 16) and cmos_l.shape == (6, 64, 64) and len(t_ax) == 12 and len(l_ax) == 16
+    assert isinstance(cmos_l, np.ndarray) and cmos_l.dtype == np.float32        # a float32 stack stays float32
+    _, cmos_h, _, _ = load_data(path, max_xy_size=64)                           # the same stage over scipy on the host
+    assert O.rel_l2(cmos_l, cmos_h) <= 1e-6
     w = {"spatial": 0.5, "spectro_temporal": 0.5}
     f = FusionCG(spc_l, cmos_l, weights=w, init_type="baseline", tol=3e-3, mask_noise=False, total_energy=1,
                  device=DEV, seed=42)
@@ -341,6 +344,32 @@ def test_readme_flow_on_a_synthetic_acquisition(tmp_path):
     assert O.rel_l2(spc_n, pb.spc) <= 1e-6 and O.rel_l2(cmos_n, pb.cmos) <= 1e-6
     # the slices the README plots afterwards (cells.ipynb): intensity image and global spectrum / decay
     assert O.rel_l2(f.marginals("tl").cpu(), torch.from_numpy(x).double().sum((0, 1))) <= 1e-6
+
+
+@pytest.mark.parametrize("shape,size", [((5, 128, 128), 64), ((3, 96, 80), 32), ((2, 30, 30), 20), ((2, 16, 16), 32),
+                                        ((2, 24, 24), 24), ((1, 100, 100), 33), ((4, 512, 512), 128), ((1, 264, 264), 8)])
+def test_load_data_resize_on_device_vs_the_scipy_restatement(shape, size):
+    """dfx_resize_stack (utils.py:420-422: Gaussian pre-filter + order-1 resize of the CMOS stack, with load_data's x/y
+    swap) against the scipy.ndimage calls skimage.transform.resize is built from.  Parity vs scikit-image itself is
+    unpinned (not installed); this pins the device kernels to the host restatement, in float64."""
+    from datafusion_amd.io import resize_like_skimage, resize_stack_on_device
+    rng = np.random.default_rng(3)
+    stack = rng.random(shape)                                                   # (z, X, Y) float64, as stored
+    ref = resize_like_skimage(np.transpose(stack, (1, 2, 0)), (size, size, shape[0]))
+    ref = np.transpose(ref, (2, 1, 0))                                          # utils.py:422
+    out = resize_stack_on_device(stack, size, DEV)
+    assert out.dtype == torch.float64 and tuple(out.shape) == (shape[0], size, size)
+    assert np.max(np.abs(out.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    plain = resize_stack_on_device(stack, size, DEV, transpose_out=False)       # without the swap
+    assert torch.equal(plain.transpose(1, 2), out)
+    o32 = resize_stack_on_device(stack.astype(np.float32), size, DEV)
+    assert o32.dtype == torch.float32 and O.rel_l2(o32.cpu(), ref) <= 1e-6
+    if shape[1] == size:                                                        # same size: the identity (up to the swap)
+        assert np.array_equal(out.cpu().numpy(), np.transpose(stack, (0, 2, 1)))
+    if shape[1] == 264:                     # shrinking 65-fold needs a Gaussian of radius 128: beyond the kernel's 64
+        from datafusion_amd import _cabi as cabi
+        with pytest.raises(cabi.DfxError, match="shrink factor too large"):
+            resize_stack_on_device(rng.random((1, 260, 260)), 4, DEV)
 
 
 def test_bench_prints_one_contract_line():
