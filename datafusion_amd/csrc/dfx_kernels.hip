@@ -1466,7 +1466,7 @@ int launch_bcast_fast(const BcastArgs &a, const dfx_plan *pl, hipStream_t st) {
 // the process ends.  In host code the array's NAME is a host-side stand-in, not a device address: host code only
 // ever uses the per-device pointer hipGetSymbolAddress returned (noalloc_scratch()), never the name.
 // ------------------------------------------------------------------------------------------
-__device__ __align__(256) double g_noalloc_scratch[DFX_NOALLOC_MAX_PS + DFX_EW_MAXBLOCKS * DFX_NPART];
+static __device__ __align__(256) double g_noalloc_scratch[DFX_NOALLOC_MAX_PS + DFX_EW_MAXBLOCKS * DFX_NPART];
 
 constexpr int kMaxDevices = 64;
 std::atomic<double *> g_noalloc_ptr[kMaxDevices];   // device address of g_noalloc_scratch on each GPU (each has its own)

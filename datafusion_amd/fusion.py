@@ -18,7 +18,9 @@ Differences from the reference a caller can observe (documented, deliberate):
   * FusionCG keeps the residual r = b - A x as its two small-space factors by default
     (`residual="factored"`; `"explicit"` stores it as a third 5-D vector, the literal fusion.py:446): same
     recurrence, same numbers, one 5-D pass per iteration instead of two;
-  * return_numpy=True copies x to the host through pinned bounce buffers (hostcopy.py): same array, ~8x sooner.
+  * return_numpy=True copies x to the host through pinned bounce buffers (hostcopy.py): same array, ~8x sooner;
+  * tensor inputs are converted to float32 (the reference keeps a torch.Tensor's dtype, fusion.py:138-139, and so
+    runs in float64 when handed float64 tensors; ndarrays are cast to float32 by both).
 """
 from __future__ import annotations
 
@@ -330,7 +332,7 @@ class FusionCG(Fusion):
     def _sweep(self, mode, eps: float | None = None) -> None:
         """One pass over x, (r,) p and everything that follows it: u(p), v(p), UU, VV, PP, XX, XP - and, when `eps` is
         given, alpha of the next iteration (fusion.py:444).
-        One GPU: the 5-D launch + ONE dfx_post_sweep launch.
+        One GPU: the 5-D launch + one dfx_post_sweep call (a reduction pass and a one-workgroup fold).
         z-sharded: the pass is cut into `comm_slices` launches along the slab axis and the all-reduce of each
         finished band of v (the RD partials, the one real exchange) is started on RCCL's stream while the
         next band is still being swept; u, UU and the scalar partials take one dfx_post_sweep launch, their all-reduce
@@ -442,7 +444,7 @@ class FusionCG(Fusion):
             else:
                 self._pending_x = True
             if self.residual == "factored" and one_gpu:                         # fusion.py:446-448, 455-456
-                k.resid_cg_step(c1, c2, eps, deferred)                          # r update, rsnew, tol, beta: 2 launches
+                k.resid_cg_step(c1, c2, eps, deferred)                          # r update, rsnew, tol, beta: 3 launches
             else:
                 if self.residual == "factored":                                 # fusion.py:446-447
                     k.resid_update(k.u, k.v, c1, c2, -1.0, cabi.S_ALPHA, True)
@@ -575,14 +577,14 @@ class FusionAdam(Fusion):
         for i in range(max_iterations):
             self.curr_iter += 1
             self._adam_step += 1
-            # one launch: the losses (fusion.py:332), d loss / d u and d loss / d v (autograd of fusion.py:216-232) and
+            # one pass + fold: the losses (fusion.py:332), d loss / d u and d loss / d v (autograd of fusion.py:216-232) and
             # exp_avg.lerp_(grad, 1 - beta1) on the first moment's two factors - all on the small arrays
             k.adam_prep(self._cmos_loc, cmask, self.spc, smask, A, B, self._m1a, self._m1b, w1, w2,
                         1.0 - self.betas[0])
             if history is not None:
                 c.sum_(k.scal[cabi.S_LOSS1:cabi.S_LOSS1 + 1])                   # the cmos term is a sum over shards
                 l1, l2 = k.scal[cabi.S_LOSS1].float(), k.scal[cabi.S_LOSS2].float()
-            # one 5-D pass (mask: fusion.py:274-278), then one launch for u(x), v(x), ||dx||^2, ||x||^2
+            # one 5-D pass (mask: fusion.py:274-278), then dfx_post_sweep for u(x), v(x), ||dx||^2, ||x||^2
             k.adam_step(x, self._m1, self._m2, A, B, cmask, lr, self.betas[0], self.betas[1], self.adam_eps,
                         self._adam_step, non_neg, m1a=self._m1a, m1b=self._m1b, fold=False)
             k.post_sweep(cabi.POST_U | cabi.POST_V | cabi.POST_FOLD_ADAM)

@@ -189,7 +189,7 @@ class HipKernels:
         after_slice(v_rows) is called after each one with the rows of self.v (viewed (nT*nL, Xs*Ys)) that
         are final - the hook the z-sharded solver uses to start their all-reduce while the sweep goes on.
         fold=False: only the 5-D launch(es) (and, with after_slice, the per-band v sums) are issued; u, v, UU and
-        PP/XX/XP are left to ONE post_sweep() launch."""
+        PP/XX/XP are left to post_sweep() (one pass + one fold launch instead of seven launches)."""
         self._chk(x, r, p)
         for t in (x, r, p):
             assert t is None or t.numel() == self.N
@@ -231,7 +231,7 @@ class HipKernels:
 
     @_on_device
     def post_sweep(self, flags: int, c1: float = 0.0, c2: float = 0.0, eps: float = 0.0) -> None:
-        """ONE launch for what follows a sweep(fold=False) or adam_step(fold=False): u and UU (POST_U), v and VV
+        """One pass + one fold launch for what follows a sweep(fold=False) or adam_step(fold=False): u and UU (POST_U), v and VV
         (POST_V; with POST_V_SUMMED self.v is already final, e.g. all-reduced, and only VV is taken), the scalar
         partials of the 5-D launch (POST_FOLD_SWEEP / POST_FOLD_ADAM), alpha of the next iteration (POST_ALPHA)."""
         g, pl = self._g()
@@ -274,7 +274,7 @@ class HipKernels:
 
     @_on_device
     def adam_prep(self, cmos, cmask, spc, smask, A, B, m1a, m1b, w1: float, w2: float, lerp_weight: float) -> None:
-        """The small-space half of a fused Adam iteration in one launch: A, B (d loss / d u, d loss / d v from
+        """The small-space half of a fused Adam iteration in one pass + its fold: A, B (d loss / d u, d loss / d v from
         self.u, self.v), the lerp of the first moment's factors (m1a, m1b; None: skip), LOSS1, LOSS2."""
         self._chk(cmos, cmask, spc, smask, A, B, m1a, m1b)
         assert cmos.numel() == A.numel() == self.S and spc.numel() == B.numel() == self.M * self.Xs * self.Ys
@@ -325,8 +325,8 @@ class HipKernels:
 
     @_on_device
     def resid_cg_step(self, c1: float, c2: float, eps: float, deferred: bool) -> None:
-        """The small-space half of a CG iteration on one GPU, two launches: ra -= ALPHA c1 u ; rb -= ALPHA c2 v ; RR ;
-        then dfx_cg_beta's bookkeeping (RSNEW, TOL, BETA, ...) by the last workgroup of the second launch."""
+        """The small-space half of a CG iteration on one GPU, three launches: ra -= ALPHA c1 u ; rb -= ALPHA c2 v ; then
+        RR and dfx_cg_beta's bookkeeping (RSNEW, TOL, BETA, ...) in the one-workgroup fold launch."""
         assert self.ra is not None
         g, _ = self._g()
         cabi.check(self._timed("resid", self.lib.dfx_resid_cg_step, g, cabi.ptr(self.ra), cabi.ptr(self.rb),
