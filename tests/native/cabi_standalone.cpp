@@ -126,6 +126,89 @@ int main() {
     HIP_OK(hipMemcpy(hu.data(), du, S * 4, hipMemcpyDeviceToHost));
     if (int rc = fetch_v(hv)) return rc;
     ok = ok && check("u(p)", hu, ru) && check("v(p)", hv, rv);
+
+    // 3. one whole CG iteration as three calls: residual update + beta, sweep left unfolded, post-sweep
+    //    with the next alpha - checked against the host on the scalars that close the iteration
+    {
+        const double c1 = 0.5 / M, c2 = 0.5 / (nZ * r * r), eps = 1e-10;
+        double *zab = dev<double>(Ps);
+        std::vector<double> h0(DFX_NSCAL);
+        HIP_OK(hipMemcpy(h0.data(), scal, DFX_NSCAL * 8, hipMemcpyDeviceToHost));
+        h0[DFX_S_RSOLD] = 3.25, h0[DFX_S_ALPHA] = 0.125;
+        HIP_OK(hipMemcpy(scal, h0.data(), DFX_NSCAL * 8, hipMemcpyHostToDevice));
+        // u, v on the device are u(p), v(p) of step 2 (hu, hv hold them); ra, rb as uploaded
+        const float *v_dev = pl.n_zchunks > 1 ? dv : v_part;
+        DFX_OK(dfx_resid_cg_step(&g, dra, drb, du, v_dev, c1, c2, eps, 1, zab, scal, part, nullptr));
+        std::vector<float> gra(S), grb(M * Ps);
+        HIP_OK(hipMemcpy(gra.data(), dra, S * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(grb.data(), drb, M * Ps * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hs.data(), scal, DFX_NSCAL * 8, hipMemcpyDeviceToHost));
+        std::vector<double> wra(S), wrb(M * Ps);
+        for (long long j = 0; j < S; ++j) wra[j] = (double)ra[j] - 0.125 * c1 * hu[j];
+        for (long long j = 0; j < M * Ps; ++j) wrb[j] = (double)rb[j] - 0.125 * c2 * hv[j];
+        ok = ok && check("ra - alpha c1 u", gra, wra) && check("rb - alpha c2 v", grb, wrb);
+        double rr = 0;      // ||bcast(ra) + bcast(rb)||^2 over the 5-D volume, from the stored fp32 factors
+        for (int m = 0; m < M; ++m)
+            for (long long j = 0; j < S; ++j) {
+                const int xi = (int)((j % ((long long)X * Y)) / Y), yi = (int)(j % Y);
+                const double t = (double)gra[j] + (double)grb[(long long)m * Ps + (xi / r) * Ys + yi / r];
+                rr += t * t;
+            }
+        const double beta_w = (double)((float)rr / ((float)3.25 + (float)eps));
+        std::printf("%-28s %.9e vs %.9e ; beta %.7e vs %.7e\n", "RR (small-space identity)", hs[DFX_S_RR], rr, hs[DFX_S_BETA], beta_w);
+        ok = ok && std::fabs(hs[DFX_S_RR] - rr) <= 1e-9 * rr && std::fabs(hs[DFX_S_BETA] - beta_w) <= 1e-6 * std::fabs(beta_w) &&
+             hs[DFX_S_RSOLD] == hs[DFX_S_RR] && hs[DFX_S_ALPHA_LAST] == 0.125 && hs[DFX_S_ITER] == 1.0;
+        // the sweep with its scalar rows left to dfx_post_sweep
+        HIP_OK(hipMemcpy(gx.data(), dx, N * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(gp.data(), dp, N * 4, hipMemcpyDeviceToHost));
+        DFX_OK(dfx_sweep_factored(DFX_SWEEP_XP, &g, &pl, dx, dra, drb, dp, scal, u_part, v_part, part, 0, pl.cpb, 0,
+                                  DFX_LAST_NOFOLD, nullptr));
+        DFX_OK(dfx_post_sweep(&g, &pl, u_part, du, v_part, pl.n_zchunks > 1 ? dv : nullptr, scal, part, 1,
+                              DFX_POST_U | DFX_POST_V | DFX_POST_FOLD_SWEEP | DFX_POST_ALPHA, c1, c2, eps, nullptr));
+        const double al = 0.125, be = hs[DFX_S_BETA];
+        double pp = 0, xxn = 0, xp = 0;
+        for (int m = 0; m < M; ++m)
+            for (long long j = 0; j < S; ++j) {
+                const long long i = (long long)m * S + j;
+                const int xi = (int)((j % ((long long)X * Y)) / Y), yi = (int)(j % Y);
+                const double res = (double)(gra[j] + grb[(long long)m * Ps + (xi / r) * Ys + yi / r]);
+                const double xn = (double)gx[i] + (double)(float)al * gp[i], pn = res + (double)(float)be * gp[i];
+                wantp[i] = (float)pn;
+                pp += pn * pn, xxn += xn * xn, xp += xn * pn;
+            }
+        project(wantp, ru, rv);
+        HIP_OK(hipMemcpy(hu.data(), du, S * 4, hipMemcpyDeviceToHost));
+        hv.resize(M * Ps);
+        HIP_OK(hipMemcpy(hv.data(), pl.n_zchunks > 1 ? dv : v_part, M * Ps * 4, hipMemcpyDeviceToHost));
+        ok = ok && check("u(p) via dfx_post_sweep", hu, ru) && check("v(p) via dfx_post_sweep", hv, rv);
+        HIP_OK(hipMemcpy(hs.data(), scal, DFX_NSCAL * 8, hipMemcpyDeviceToHost));
+        double uu2 = 0, vv2 = 0;
+        for (float t : hu) uu2 += (double)t * t;
+        for (float t : hv) vv2 += (double)t * t;
+        const double alpha_w = (double)((float)hs[DFX_S_RSOLD] / ((float)(c1 * uu2 + c2 * vv2) + (float)eps));
+        std::printf("%-28s PP %.6e/%.6e XX %.6e/%.6e XP %.6e/%.6e alpha %.7e/%.7e\n", "post-sweep scalars", hs[DFX_S_PP], pp,
+                    hs[DFX_S_XX], xxn, hs[DFX_S_XP], xp, hs[DFX_S_ALPHA], alpha_w);
+        ok = ok && std::fabs(hs[DFX_S_PP] - pp) <= 1e-5 * pp && std::fabs(hs[DFX_S_XX] - xxn) <= 1e-5 * xxn &&
+             std::fabs(hs[DFX_S_XP] - xp) <= 1e-5 * std::fabs(xp) + 1e-7 * std::sqrt(pp * xxn) &&
+             std::fabs(hs[DFX_S_UU] - uu2) <= 1e-9 * uu2 && std::fabs(hs[DFX_S_VV] - vv2) <= 1e-9 * vv2 &&
+             std::fabs(hs[DFX_S_ALPHA] - alpha_w) <= 1e-6 * std::fabs(alpha_w);
+        // 4. the entry point that takes no workspace gives what the one with a workspace gives
+        std::vector<float> a1(S), b1(M * Ps), a2(S), b2(M * Ps);
+        DFX_OK(dfx_resid_update(&g, dra, drb, du, pl.n_zchunks > 1 ? dv : v_part, 0.3f, -0.7f, 1.5f, nullptr, 0, zab, scal,
+                                part, nullptr));
+        HIP_OK(hipMemcpy(a1.data(), dra, S * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(b1.data(), drb, M * Ps * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hs.data(), scal, DFX_NSCAL * 8, hipMemcpyDeviceToHost));
+        const double rr1 = hs[DFX_S_RR];
+        DFX_OK(dfx_resid_update_noalloc(&g, dra, drb, du, pl.n_zchunks > 1 ? dv : v_part, 0.3f, -0.7f, 1.5f, nullptr, 0,
+                                        scal, nullptr));
+        HIP_OK(hipMemcpy(a2.data(), dra, S * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(b2.data(), drb, M * Ps * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hs.data(), scal, DFX_NSCAL * 8, hipMemcpyDeviceToHost));
+        const bool same = a1 == a2 && b1 == b2 && hs[DFX_S_RR] == rr1;
+        std::printf("%-28s %s\n", "dfx_resid_update_noalloc", same ? "bit-identical" : "DIFFERS");
+        ok = ok && same;
+    }
     HIP_OK(hipDeviceSynchronize());
     std::printf(ok ? "cabi_standalone: OK\n" : "cabi_standalone: MISMATCH\n");
     return ok ? 0 : 1;
