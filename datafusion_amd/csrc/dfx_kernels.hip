@@ -269,7 +269,11 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
                                             f4 (&uacc)[ZC], double &dpp, double &dxx, double &dxp) {
     float *vbase = a.v_part + (long long)blockIdx.y * a.q.M * a.q.Ps;
     const int lane = threadIdx.x & 63;
-    constexpr int ZB = ZC < DFX_ZB ? ZC : DFX_ZB;
+    // the ZN live planes go in groups of DFX_ZB (loads issued together, then updated and stored); the LAST group takes
+    // the remainder too (ZN = 5 -> 2 + 3, 7 -> 2 + 2 + 3), so that no group runs with fewer loads in flight than the
+    // others (5 as 2 + 2 + 1 cost three group latencies for five planes: 87 % of the per-plane rate of 4 or 8)
+    constexpr int NG = (ZN / DFX_ZB) > 0 ? ZN / DFX_ZB : 1;
+    constexpr int GS = (2 * DFX_ZB - 1) < ZN ? (2 * DFX_ZB - 1) : ZN;     // largest group
     for (int m = m0; m < m1; m += ms) {
         const long long base = (long long)m * a.q.S + off;
         f4 s4 = {0.f, 0.f, 0.f, 0.f};
@@ -277,11 +281,13 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
         f4 rb4 = {0.f, 0.f, 0.f, 0.f};
         if (FACT) rb4 = L.bload(a.rb + (long long)m * a.q.Ps);
 #pragma unroll
-        for (int g = 0; g < ZC; g += ZB) {
-            f4 xv[ZB], rv[ZB], pv[ZB];
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = gi * DFX_ZB;
+            const int cnt = (gi == NG - 1) ? ZN - g : DFX_ZB;
+            f4 xv[GS], rv[GS], pv[GS];
 #pragma unroll
-            for (int j = 0; j < ZB; ++j) {
-                if (g + j < ZN) {
+            for (int j = 0; j < GS; ++j) {
+                if (j < cnt) {
                     const long long i = base + (long long)(g + j) * a.q.P;
                     if (MODE == DFX_SWEEP_PROJECT) {
                         xv[j] = ld4s(a.x + i);
@@ -299,8 +305,8 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
                 }
             }
 #pragma unroll
-            for (int j = 0; j < ZB; ++j) {
-                if (g + j < ZN) {
+            for (int j = 0; j < GS; ++j) {
+                if (j < cnt) {
                     const long long i = base + (long long)(g + j) * a.q.P;
                     f4 pn;
                     if (MODE == DFX_SWEEP_PROJECT) {
@@ -561,7 +567,8 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
                                               long long off, const f4 (&av)[ZC], const f4 (&mk)[ZC],
                                               const f4 (&m1av)[ZC], f4 (&uacc)[ZC], float *vbase, int lane,
                                               double &ddd, double &dxx) {
-    constexpr int ZB = ZC < DFX_ADAM_ZB ? ZC : DFX_ADAM_ZB;
+    constexpr int NG = (ZN / DFX_ADAM_ZB) > 0 ? ZN / DFX_ADAM_ZB : 1;      // groups as in sweep_steps: the last one
+    constexpr int GS = (2 * DFX_ADAM_ZB - 1) < ZN ? (2 * DFX_ADAM_ZB - 1) : ZN;   // takes the remainder
     for (int m = m0; m < m1e; m += gz) {
         const long long base = (long long)m * a.q.S + off;
         const f4 b4 = L.bload(a.B + (long long)m * a.q.Ps);
@@ -570,11 +577,13 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
         f4 s4 = {0.f, 0.f, 0.f, 0.f};
         float dd = 0.f, xx = 0.f;
 #pragma unroll
-        for (int g = 0; g < ZC; g += ZB) {
-            f4 xv[ZB], e1[ZB], e2[ZB];
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = gi * DFX_ADAM_ZB;
+            const int cnt = (gi == NG - 1) ? ZN - g : DFX_ADAM_ZB;
+            f4 xv[GS], e1[GS], e2[GS];
 #pragma unroll
-            for (int j = 0; j < ZB; ++j) {
-                if (g + j < ZN) {
+            for (int j = 0; j < GS; ++j) {
+                if (j < cnt) {
                     const long long i = base + (long long)(g + j) * a.q.P;
                     xv[j] = ld4s(a.x + i);
                     if (!M1F) e1[j] = ld4s(a.m1 + i);
@@ -582,8 +591,8 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
                 }
             }
 #pragma unroll
-            for (int j = 0; j < ZB; ++j) {
-                if (g + j < ZN) {
+            for (int j = 0; j < GS; ++j) {
+                if (j < cnt) {
                     const int k = g + j;
                     const long long i = base + (long long)k * a.q.P;
                     f4 gr = av[k] + b4;
