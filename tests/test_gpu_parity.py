@@ -696,3 +696,36 @@ def test_fused_small_space_launches_equal_the_stand_alone_entry_points(dims):
     assert torch.equal(xa, xb) and torch.equal(m2a, m2b) and torch.equal(ka.u, kb.u) and torch.equal(ka.v, kb.v)
     sl = [cabi.S_ADAM_DD, cabi.S_ADAM_XX]
     assert torch.equal(ka.scal[sl], kb.scal[sl])
+
+
+def test_second_call_continues_from_x_and_runs_are_bit_reproducible():
+    """Re-entrancy: a second __call__ continues from the current x with a fresh r, p (CG) or a fresh
+    optimizer (Adam), like the reference objects do; and two identical solves give identical bits (no atomics, fixed
+    reduction orders)."""
+    from datafusion_amd import FusionAdam, FusionCG
+    w = {"spatial": 0.5, "spectro_temporal": 0.5}
+    spc, cmos = O.cells_like_inputs(8, 4, 5, 64, 4, seed=23)
+    for residual in ("factored", "explicit"):
+        f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV, residual=residual)
+        f(3, return_numpy=False)
+        x, _, _ = f(4)
+        assert f.curr_iter == 7
+        pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
+        O.cg(pb, 3, with_loss=False)
+        xo = O.cg(pb, 4, with_loss=False)
+        assert O.rel_l2(x, xo) <= TIGHT
+        g = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV, residual=residual)
+        g(3, return_numpy=False)
+        x2, _, _ = g(4)
+        assert np.array_equal(x, x2)
+    f = FusionAdam(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV)
+    f(lr=1e-7, max_iterations=2, return_numpy=False)
+    x, _, _ = f(lr=1e-7, max_iterations=3)
+    pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None)
+    O.adam(pb, 1e-7, 2)
+    xo = O.adam(pb, 1e-7, 3)
+    assert f.curr_iter == 5 and O.rel_l2(x, xo) <= TIGHT
+    g = FusionAdam(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV)
+    g(lr=1e-7, max_iterations=2, return_numpy=False)
+    x2, _, _ = g(lr=1e-7, max_iterations=3)
+    assert np.array_equal(x, x2)
