@@ -33,6 +33,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef DFX_WAVES
 #define DFX_WAVES 4       // waves per workgroup of the fast kernels (each wave owns one wave tile)
 #endif
+#ifndef DFX_APPLY_UNROLL
+#define DFX_APPLY_UNROLL 1   // float4 groups per array a lane of k_adam_apply loads before it stores (C2: 1: 5.35 ms, 2: 5.67, 4: 5.62)
+#endif
 #ifndef DFX_ADAM_ZB
 #define DFX_ADAM_ZB 2     // same for k_adam_fast
 #endif
@@ -673,6 +676,55 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     block_store3(ddd, dxx, 0.0, a.part + bid * DFX_NPART);
+}
+
+// torch.optim.Adam's step on an EXPLICIT gradient (the autograd formulation, fusion.py:338-342: loss.backward() has
+// left x.grad, optimizer.step() consumes it): x, grad, exp_avg, exp_avg_sq read, x, exp_avg, exp_avg_sq written - 7N
+// words in one launch (torch's own fused implementation takes 52 launches per step on a 4 GiB tensor, 7.6 ms at C2).
+// Workgroup b takes the float4 groups b, b + gridDim, ...: the chip streams one contiguous moving window per array.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_adam_apply(float *x, const float *g, float *m1, float *m2, long long n,
+                                                    AdamArgs a) {
+    double ddd = 0, dxx = 0;
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += stride * UNROLL) {
+        f4 xv[UNROLL], gv[UNROLL], e1[UNROLL], e2[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long long i = i0 + u * stride;
+            if (i < n4) {
+                xv[u] = ld4s(x + 4 * i);
+                gv[u] = ld4s(g + 4 * i);
+                e1[u] = ld4s(m1 + 4 * i);
+                e2[u] = ld4s(m2 + 4 * i);
+            }
+        }
+        float dd = 0.f, xx = 0.f;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long long i = i0 + u * stride;
+            if (i < n4) {
+                const f4 xn = adam_elem4<false>(xv[u], gv[u], e1[u], e2[u], a);
+                st4s(x + 4 * i, xn);
+                st4s(m1 + 4 * i, e1[u]);
+                st4s(m2 + 4 * i, e2[u]);
+                const f4 d = xn - xv[u];
+                dd += dot4(d, d);
+                xx += dot4(xn, xn);
+            }
+        }
+        ddd += (double)dd;
+        dxx += (double)xx;
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {   // tail (n % 4)
+        float e1 = m1[i], e2 = m2[i];
+        const float xo = x[i], xn = adam_elem<false>(xo, g[i], e1, e2, a);
+        x[i] = xn, m1[i] = e1, m2[i] = e2;
+        ddd += (double)((xn - xo) * (xn - xo));
+        dxx += (double)(xn * xn);
+    }
+    block_store3(ddd, dxx, 0.0, a.part + (long long)blockIdx.x * DFX_NPART);
 }
 
 __global__ __launch_bounds__(256) void k_gen_adam(AdamArgs a) {
@@ -1857,6 +1909,38 @@ int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, cons
     if (!m1a || !m1b) return fail(DFX_EINVAL, "dfx_adam_step_factored: NULL buffer");
     return adam_impl(g, pl, x, nullptr, m1a, m1b, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, scal, u_part,
                      v_part, part, stream);
+}
+
+int dfx_adam_apply(float *x, const float *grad, float *m1, float *m2, int64_t n, double lr, double beta1,
+                   double beta2, double eps, int32_t step, int32_t flags, int32_t n_blocks, double *scal, double *part,
+                   void *stream) {
+    if (!x || !grad || !m1 || !m2 || !scal || !part || n <= 0) return fail(DFX_EINVAL, "dfx_adam_apply: bad argument");
+    if (step < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1))
+        return fail(DFX_EINVAL, "dfx_adam_apply: step >= 1 and betas in [0, 1) required");
+    if (!aligned16(x) || !aligned16(grad) || !aligned16(m1) || !aligned16(m2))
+        return fail(DFX_EALIGN, "dfx_adam_apply: x, grad, m1, m2 must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamArgs a{};
+    a.part = part;
+    a.b1 = (float)beta1, a.b2 = (float)beta2, a.omb1 = (float)(1.0 - beta1), a.omb2 = (float)(1.0 - beta2);
+    a.eps = (float)eps, a.step_size = (float)(lr / bc1), a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.non_neg = (flags & DFX_ADAM_NONNEG) ? 1 : 0;
+    int nb = n_blocks;
+    if (nb <= 0) {      // one workgroup of four waves per CU, like the sweep
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        (void)hipGetLastError();
+        nb = cus;
+    }
+    const long long need = ((n >> 2) + 255) / 256;
+    if (nb > need) nb = (int)(need < 1 ? 1 : need);
+    if (nb > DFX_EW_MAXBLOCKS) nb = DFX_EW_MAXBLOCKS;
+    hipLaunchKernelGGL(k_adam_apply<DFX_APPLY_UNROLL>, dim3(nb), dim3(256), 0, st, x, grad, m1, m2, (long long)n, a);
+    DFX_LAUNCH_CHECK("dfx_adam_apply");
+    return fold(part, nb, 2, scal + DFX_S_ADAM_DD, 1.0, st);
 }
 
 int dfx_adam_prep(const float *u, const float *cmos, const float *cmask, float *A, float *m1a, int64_t n_u,

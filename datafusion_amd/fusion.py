@@ -600,25 +600,23 @@ class FusionAdam(Fusion):
                 history[i] = [float(l1), float(l2), float(l1) + float(l2)]
 
     def _run_autograd(self, lr, max_iterations, non_neg, history):
-        optimizer = torch.optim.Adam([self.x], lr=lr, betas=self.betas, eps=self.adam_eps, amsgrad=False)
+        """fusion.py:324-358 as written there - loss() through autograd, an optimizer step on the explicit gradient -
+        with the loss as one autograd node over the HIP kernels and torch.optim.Adam's update as one launch (DfxAdam:
+        the clamp of fusion.py:344-346 and the norms of the tolerance are fused into it)."""
+        optimizer = self.k.adam_optimizer([self.x], lr, self.betas, self.adam_eps, non_neg)     # DfxAdam
         for i in range(max_iterations):
             self.curr_iter += 1
-            prev_x = self.x.detach().clone() if self.tol is not None else None
             optimizer.zero_grad()
             # the gradient mask of fusion.py:274-278 is applied inside the backward kernel
             spatial_loss, spectro_temporal_loss = self.loss_autograd(mask_grad=self.mask_noise)
             loss = spatial_loss + spectro_temporal_loss
             loss.backward()
-            optimizer.step()
-            if non_neg:                                                         # fusion.py:344-346
-                with torch.no_grad():
-                    self.x.clamp_(min=0)
+            optimizer.step()                                                    # + clamp (fusion.py:344-346)
             tolerance = None
             if self.tol is not None:                                            # fusion.py:348
-                with torch.no_grad():
-                    d = torch.stack([((self.x - prev_x) ** 2).sum(), (self.x.detach() ** 2).sum()]).double()
-                    self.comm.sum_(d)
-                    tolerance = float(torch.sqrt(d[0] / d[1]))
+                d = optimizer.last_sq_norms.clone()                             # ||x - prev_x||^2, ||x||^2
+                self.comm.sum_(d)
+                tolerance = float(torch.sqrt(d[0] / d[1]))
             if tolerance is not None and tolerance < self.tol:
                 break
             if history is not None:

@@ -285,6 +285,12 @@ class HipKernels:
                                0 if smask is None else smask.numel(), cabi.ptr(B), cabi.ptr(m1b), B.numel(), w1, w2,
                                lerp_weight, cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_adam_prep")
 
+    @staticmethod
+    def adam_optimizer(params, lr, betas, eps, non_neg):
+        """The optimizer of the autograd formulation (fusion.py:325): torch.optim.Adam's update as one launch."""
+        from .optim import DfxAdam
+        return DfxAdam(params, lr=lr, betas=betas, eps=eps, non_neg=non_neg)
+
     @_on_device
     def lerp(self, m, g, weight: float) -> None:
         """m += weight * (g - m) on small arrays (torch's exp_avg.lerp_)."""

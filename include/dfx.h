@@ -206,6 +206,16 @@ int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, cons
                            float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
                            double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
                            float *v_part, double *part, void *stream);
+/* torch.optim.Adam's step (amsgrad=False, weight_decay=0) on an EXPLICIT gradient: the optimizer.step() of
+ * fusion.py:342 when loss.backward() (fusion.py:338) has materialised x.grad - the autograd formulation, e.g. with
+ * extra differentiable terms added to the loss.  x, grad, m1 (exp_avg), m2 (exp_avg_sq): n floats each, 16-byte
+ * aligned; one launch, 7n words.  flags: DFX_ADAM_NONNEG fuses the clamp of fusion.py:344-346.
+ * scal[ADAM_DD] = ||x_new - x_old||^2, scal[ADAM_XX] = ||x_new||^2 (the tolerance of fusion.py:244-252 without the
+ * clone of fusion.py:329).  n_blocks <= 0: one workgroup per CU.  part: DFX_EW_MAXBLOCKS * DFX_NPART doubles. */
+int dfx_adam_apply(float *x, const float *grad, float *m1, float *m2, int64_t n, double lr, double beta1,
+                   double beta2, double eps, int32_t step, int32_t flags, int32_t n_blocks, double *scal, double *part,
+                   void *stream);
+
 /* The small-space half of one fused Adam iteration in ONE launch (fusion.py:332-338: loss(), and what
  * loss.backward() does on the cmos- and spc-sized arrays):
  *   A[i] = -2 w1 cmask[i] (cmos[i] - u[i]), i < n_u ;  B[i] = -2 w2 smask[i % smask_n] (spc[i] - v[i]), i < n_v

@@ -11,7 +11,29 @@ import torch
 from datafusion_amd import _cabi as cabi
 
 
+class _CpuAdam(torch.optim.Adam):
+    """Stand-in for datafusion_amd.optim.DfxAdam: torch.optim.Adam + the fused clamp and the two squared norms."""
+
+    def __init__(self, params, lr, betas, eps, non_neg):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, amsgrad=False)
+        self.non_neg, self.last_sq_norms = non_neg, None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        p = self.param_groups[0]["params"][0]
+        prev = p.detach().clone()
+        out = super().step(closure)
+        if self.non_neg:
+            p.clamp_(min=0)
+        self.last_sq_norms = torch.stack([((p - prev).double() ** 2).sum(), (p.double() ** 2).sum()])
+        return out
+
+
 class CpuStandIn:
+    @staticmethod
+    def adam_optimizer(params, lr, betas, eps, non_neg):
+        return _CpuAdam(params, lr, betas, eps, non_neg)
+
     def __init__(self, n_t, n_l, n_z_local, X, Y, r, device, target_blocks=0):
         self.device = torch.device("cpu")
         self.shape = (n_t, n_l, n_z_local, X, Y)

@@ -729,3 +729,37 @@ def test_second_call_continues_from_x_and_runs_are_bit_reproducible():
     g(lr=1e-7, max_iterations=2, return_numpy=False)
     x2, _, _ = g(lr=1e-7, max_iterations=3)
     assert np.array_equal(x, x2)
+
+
+@pytest.mark.parametrize("n,non_neg", [(4 * 1024 * 257, False), (1003, True), (3, False), (1 << 22, True)])
+def test_dfx_adam_optimizer_matches_torch_optim_adam(n, non_neg):
+    """DfxAdam (dfx_adam_apply: one launch, explicit gradient) against torch.optim.Adam(amsgrad=False) over several
+    steps, with the fused clamp of fusion.py:344-346 and the two squared norms the tolerance needs."""
+    from datafusion_amd import DfxAdam
+    torch.manual_seed(7)
+    x0 = torch.randn(n, device=DEV)
+    grads = [torch.randn(n, device=DEV) * (0.1 + k) for k in range(4)]
+    pa, pb = torch.nn.Parameter(x0.clone()), torch.nn.Parameter(x0.clone())
+    oa = torch.optim.Adam([pa], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, amsgrad=False)
+    ob = DfxAdam([pb], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, non_neg=non_neg)
+    for g in grads:
+        prev = pa.detach().clone()
+        pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step()
+        if non_neg:
+            with torch.no_grad():
+                pa.copy_(pa.data.clamp(min=0))
+        ob.step()
+        assert O.rel_l2(pb.detach().cpu(), pa.detach().cpu()) <= 1e-6
+        dd, xx = float(((pa.detach() - prev).double() ** 2).sum()), float((pa.detach().double() ** 2).sum())
+        got = ob.last_sq_norms.cpu()
+        assert abs(float(got[0]) - dd) <= 1e-5 * dd + 1e-12 and abs(float(got[1]) - xx) <= 1e-5 * xx
+    sa, sb = oa.state[pa], ob.state[pb]
+    assert int(sb["step"]) == 4
+    assert O.rel_l2(sb["exp_avg"].cpu(), sa["exp_avg"].cpu()) <= 1e-6
+    assert O.rel_l2(sb["exp_avg_sq"].cpu(), sa["exp_avg_sq"].cpu()) <= 1e-6
+    cpu_p = torch.nn.Parameter(torch.zeros(8))
+    cpu_p.grad = torch.ones(8)
+    from datafusion_amd import _cabi as cabi
+    with pytest.raises(cabi.DfxError):
+        DfxAdam([cpu_p], lr=1e-2).step()                      # no CPU path
