@@ -406,3 +406,25 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                     str(src), "-o", str(exe), "-L", lib_dir, "-ldfx", f"-Wl,-rpath,{lib_dir}"], check=True)
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_host_code_of_the_library_under_asan_and_ubsan(tmp_path):
+    """libdfx's host side (planner, argument validation of every entry point) built with AddressSanitizer + UBSan
+    (host code only: -Xarch_host) and driven over 20 000 random geometries by tests/native/host_sanitize.cpp.  Every
+    call there returns before launching anything, so no GPU is needed."""
+    import shutil
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not (shutil.which("hipcc") and os.path.exists(clang)):
+        pytest.skip("hipcc / clang++ not available")
+    lib, exe = tmp_path / "libdfx_san.so", tmp_path / "host_sanitize"
+    san = ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host",
+           "-fno-sanitize-recover=undefined"]
+    subprocess.check_call(["hipcc", "-O1", "-g", "--offload-arch=gfx950", "-shared", "-fPIC", *san, "-o", str(lib),
+                           os.path.join(ROOT, "datafusion_amd", "csrc", "dfx_kernels.hip")], cwd=ROOT)
+    subprocess.check_call([clang, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o",
+                           str(exe), os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), str(lib),
+                           f"-Wl,-rpath,{tmp_path}"], cwd=ROOT)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert p.returncode == 0 and "host_sanitize: OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
