@@ -682,6 +682,9 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
 // left x.grad, optimizer.step() consumes it): x, grad, exp_avg, exp_avg_sq read, x, exp_avg, exp_avg_sq written - 7N
 // words in one launch (torch's own fused implementation takes 52 launches per step on a 4 GiB tensor, 7.6 ms at C2).
 // Workgroup b takes the float4 groups b, b + gridDim, ...: the chip streams one contiguous moving window per array.
+// Measured at C2 (tools/tune_adam_apply.py): 5.35 ms = 5.6 TB/s with one workgroup per CU and one group per array
+// loaded before the stores; 2 or 4 groups 5.6 - 5.7 ms, 512 - 2048 workgroups 5.8 - 6.5 ms, runs of 4 - 64 consecutive
+// 4 KiB pieces per workgroup 5.47 - 5.49 ms: seven streams top out here (six: 6.0 TB/s, four: 6.4).
 template <int UNROLL>
 __global__ __launch_bounds__(256) void k_adam_apply(float *x, const float *g, float *m1, float *m2, long long n,
                                                     AdamArgs a) {
