@@ -763,3 +763,31 @@ def test_dfx_adam_optimizer_matches_torch_optim_adam(n, non_neg):
     from datafusion_amd import _cabi as cabi
     with pytest.raises(cabi.DfxError):
         DfxAdam([cpu_p], lr=1e-2).step()                      # no CPU path
+
+
+def test_cg_iterations_can_be_captured_in_a_hip_graph():
+    """With tol=None the loop body neither allocates nor synchronises and reads alpha, beta from device memory, so
+    iterate(n) can be captured into a HIP graph (torch.cuda.CUDAGraph) and replayed: 2 eager + 2 replays of 5 captured
+    iterations give the bits of 12 eager iterations."""
+    from datafusion_amd import FusionCG
+    w = {"spatial": 0.5, "spectro_temporal": 0.5}
+    spc, cmos = O.synthetic_inputs(8, 4, 4, 64, 4, seed=3)
+    a = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV)
+    a.start()
+    a.iterate(12)
+    a.finish()
+    b = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=None, device=DEV)
+    b.start()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        b.iterate(2)                                   # warm-up on a side stream, as torch asks before a capture
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        b.iterate(5)                                   # recorded, not executed
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    b.finish()
+    assert torch.equal(a.x, b.x) and torch.equal(a.k.scal[:12], b.k.scal[:12])
