@@ -58,6 +58,7 @@ class HipKernels:
                        if self.plan.n_zchunks > 1 else None)
         self.v = self._v_own if self._v_own is not None else self.v_part.view(n_t, n_l, self.Xs, self.Ys)
         self.ra = self.rb = self.zab = None   # factored residual (new_factored_residual)
+        self._last_slices = 1                 # launches the last sweep was cut into (post_sweep folds that many row sets)
         self.timing = None   # bench.py sets a dict: name -> list of (start, end) torch.cuda.Event pairs
         self.timing_names = None   # ... and, to time only some entry points (an event pair costs ~2 us of stream time), their names
 
@@ -239,7 +240,7 @@ class HipKernels:
         cabi.check(self._timed("post", self.lib.dfx_post_sweep, g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u),
                                cabi.ptr(self.v if summed else self.v_part),
                                None if summed or self._v_own is None else cabi.ptr(self._v_own),
-                               cabi.ptr(self.scal), cabi.ptr(self.part), getattr(self, "_last_slices", 1), flags,
+                               cabi.ptr(self.scal), cabi.ptr(self.part), self._last_slices, flags,
                                c1, c2, eps, self._stream()), "dfx_post_sweep")
 
     @_on_device
