@@ -148,33 +148,96 @@ def bench_adam(a, world, rank, dev, group, use_dist):
         dist.destroy_process_group()
 
 
+COMMITTED_C3_ONE_GPU_ITS = 11.1    # profiles/r02_bench_one_rank_rccl_with_config3_strong_leg.json: config 3 whole on one MI355X
+
+
 def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
     """N > 1 only, same invocation as the weak-scaled headline: BASELINE.json configs[2] (t512 x l32 x z32 x 256 x 256,
     2^35 elements, 128 GiB per vector - more than one GPU holds with the reference's three vectors) STRONG-scaled:
-    32 / N planes per rank, total work fixed.  The one-GPU anchor is measured here too: rank 0 alone runs the whole
-    volume on its GPU (it fits with the factored residual: x + p = 256 GiB) while the other ranks wait."""
+    32 / N planes per rank, total work fixed.  The one-GPU anchor is measured here too, FIRST (before the sharded
+    legs have used the memory): rank 0 alone runs the whole volume on its GPU (it fits with the factored residual:
+    x + p = 256 GiB) while the other ranks wait at a barrier; three timed blocks, the median is the anchor and their
+    spread is reported.  A failure of the anchor (e.g. not enough free memory) is recorded, not fatal: the efficiency
+    against the committed one-GPU figure is always there."""
     n_t, n_l, n_z, xy, r = WORKLOADS["c3"]
     if n_z % world:
         return {"skipped": f"{n_z} z-planes do not split evenly over {world} ranks"}
     steps, warmup = min(a.steps, 20), min(a.warmup, 3)
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
-    res = run(a.residual, spc=spc, cmos=cmos, grp=group, steps=steps, warmup=warmup)
     anchor = None
-    if rank == 0 and torch.cuda.mem_get_info()[0] >= 270 * 2 ** 30:
-        one = run("factored", spc=spc, cmos=cmos, grp=None, steps=min(steps, 10), warmup=2)
-        anchor = {"iters_per_s": one["its"], "ms_per_step": one["dt"] / one["steps"] * 1e3, "sweep_ms": one["sweep_ms"],
-                  "roofline_frac": one["sweep_bytes"] / (one["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                  "note": "the whole volume on rank 0's GPU alone, factored residual, measured in this invocation"}
+    if rank == 0:
+        try:
+            if torch.cuda.mem_get_info()[0] < 270 * 2 ** 30:
+                raise RuntimeError(f"only {torch.cuda.mem_get_info()[0] / 2**30:.0f} GiB free on rank 0's GPU")
+            one = run("factored", spc=spc, cmos=cmos, grp=None, steps=min(steps, 10), warmup=2, repeats=3)
+            blocks = one["block_ms_per_step"]
+            anchor = {"iters_per_s": one["its"], "ms_per_step": one["dt"] / one["steps"] * 1e3,
+                      "block_ms_per_step": blocks, "anchor_spread": (max(blocks) - min(blocks)) / sorted(blocks)[len(blocks) // 2],
+                      "sweep_ms": one["sweep_ms"], "placement": one["placement"],
+                      "roofline_frac": one["sweep_bytes"] / (one["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "note": "the whole volume on rank 0's GPU alone, factored residual, measured first in this "
+                              "invocation; median of three timed blocks"}
+        except Exception as e:  # noqa: BLE001 - the anchor must not take the sharded measurement down with it
+            anchor = {"failed": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
     dist.barrier()
+    res = run(a.residual, spc=spc, cmos=cmos, grp=group, steps=steps, warmup=warmup)
     its = res["its"]
+    ok = anchor is not None and "iters_per_s" in anchor
     out = {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r} (BASELINE configs[2]), {n_z // world} "
                        f"z-planes per GPU", "scaling": "strong", "n_gpus": world, "n_elements": res["n_local"] * world,
            "iters_per_s": its, "ms_per_step": res["dt"] / res["steps"] * 1e3, "steps": res["steps"],
+           "block_ms_per_step": res["block_ms_per_step"],
            "hbm_moved_GBps_per_gpu": 4.0 * res["iter_words"] * res["n_local"] * its / 1e9,
            "kernel_ms": res["kern"], "roofline": roofline(res, a.residual, (None, "none: not profiled"), r=r),
-           "comm": res.get("comm"), "one_gpu_anchor": anchor,
-           "strong_scaling_efficiency": (its / (world * anchor["iters_per_s"])) if anchor else None}
+           "comm": res.get("comm"), "placement": res["placement"], "one_gpu_anchor": anchor,
+           "strong_scaling_efficiency": (its / (world * anchor["iters_per_s"])) if ok else None,
+           "strong_scaling_efficiency_vs_committed_one_gpu_figure": its / (world * COMMITTED_C3_ONE_GPU_ITS),
+           "committed_one_gpu_iters_per_s": COMMITTED_C3_ONE_GPU_ITS}
     return out
+
+
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start one rank per GPU as CHILD processes
+    (python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>), pass rank 0's ONE JSON line through
+    to stdout, and return non-zero - with the tail of the children's stderr repeated - if any rank fails.  This parent
+    never initialises a GPU (torch.cuda.device_count() does not) and never replaces itself with another program."""
+    import collections
+    import socket
+    import subprocess
+    import threading
+    found = torch.cuda.device_count()
+    if found < n_gpus:
+        sys.stderr.write(f"bench.py --gpus {n_gpus}: needs {n_gpus} GPUs, found {found}\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stderr.write("bench.py: starting " + " ".join(cmd) + "\n")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    tail = collections.deque(maxlen=60)
+
+    def pump():
+        for ln in p.stderr:
+            tail.append(ln)
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    out = p.stdout.read()
+    rc = p.wait()
+    th.join(timeout=10)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if rc == 0 and len(lines) == 1:
+        os.write(_REAL_STDOUT, (lines[0] + "\n").encode())
+        return 0
+    sys.stderr.write(f"bench.py: the {n_gpus}-rank run failed (exit code {rc}, {len(lines)} result line(s)); last "
+                     f"lines of its stderr:\n" + "".join(tail))
+    return rc if rc else 1
 
 
 def emit(obj):
@@ -206,16 +269,23 @@ def main():
                     help="--method adam: first moment as two small-space factors (4N words/iter) or a 5-D vector (6N)")
     ap.add_argument("--comm-slices", default="auto",
                     help="launches a z-sharded sweep is cut into (overlap of the v all-reduce): auto or a number")
+    ap.add_argument("--placement", default="rank", choices=["rank", "probe", "plain"],
+                    help="placement of vectors >= 8 GiB: rank (by measured memory class, default) | probe (round-2 candidate probe) | plain")
     ap.add_argument("--single", action="store_true", help="time only --residual, not the other representation as well")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--target-blocks", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed blocks of exactly --steps iterations each; value / ms_per_step are the median block's")
     a = ap.parse_args()
 
+    if "RANK" not in os.environ and (a.gpus > 1 or os.environ.get("DFX_FORCE_COMM") == "1"):
+        # `python bench.py --gpus N` as the driver runs it: this process starts the N ranks itself and never touches a GPU
+        sys.exit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     group = None
@@ -233,12 +303,13 @@ def main():
     n_z = nz_gpu * world
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
 
-    def run(residual, spc=spc, cmos=cmos, grp=group, steps=a.steps, warmup=a.warmup):
-        """Construct, warm up, time exactly `steps` iterations of one residual mode; max over ranks."""
+    def run(residual, spc=spc, cmos=cmos, grp=group, steps=a.steps, warmup=a.warmup, repeats=a.repeats):
+        """Construct, warm up, time `repeats` blocks of exactly `steps` iterations of one residual mode (each block
+        bracketed by barrier + synchronize on both sides, max over ranks); the MEDIAN block is the result."""
         sharded = grp is not None
         f = FusionCG(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
                      mask_noise=False, total_energy=1, device=dev, seed=42, group=grp, defer_x=not a.no_defer,
-                     target_blocks=a.target_blocks, residual=residual, comm_slices=a.comm_slices if a.comm_slices == "auto" else int(a.comm_slices))
+                     target_blocks=a.target_blocks, residual=residual, placement=a.placement, comm_slices=a.comm_slices if a.comm_slices == "auto" else int(a.comm_slices))
         fact = residual == "factored"
         sweep_name = ("sweep2" if a.no_defer else "sweep1") + ("f" if fact else "")
 
@@ -252,11 +323,13 @@ def main():
         f.iterate(warmup)
         # the timed region: HIP events bracket the dominant kernel only (roofline.achieved comes from them) ...
         f.k.timing, f.k.timing_names = {}, {sweep_name}
-        fence_()
-        t0 = time.perf_counter()
-        f.iterate(steps)
-        fence_()
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(max(1, repeats)):
+            fence_()
+            t0 = time.perf_counter()
+            f.iterate(steps)
+            fence_()
+            dts.append(time.perf_counter() - t0)
         timing = f.k.timing
         # ... the other entry points, and the waits for collectives, are timed in a second, untimed loop (kernel_ms and
         # comm are breakdowns, not the metric)
@@ -269,20 +342,24 @@ def main():
             timing.setdefault(name, evs)
         f.finish()  # raises if the residual ever went non-finite
         if sharded:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor(dts, dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t)
-        # per-iteration time of each entry point from the HIP events recorded on the launch stream inside the
-        # timed region (a z-sharded sweep is cut into several launches: sum them)
-        kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps for name, evs in timing.items()}
+            dts = [float(v) for v in t]
+        dt = sorted(dts)[len(dts) // 2]
+        # per-iteration time of each entry point from the HIP events recorded on the launch stream inside the timed
+        # blocks (the dominant kernel: all blocks) or the detail loop (a z-sharded sweep is cut into several launches:
+        # sum them)
+        kern = {name: sum(e0.elapsed_time(e1) for e0, e1 in evs) / (steps * (len(dts) if name == sweep_name else 1))
+                for name, evs in timing.items()}
         # words the sweep must move: x, p read + written (deferred x update) or p read + written, plus
         # the read of r when it is an explicit 5-D vector
         sweep_words = (2 if a.no_defer else 4) + (0 if fact else 1)
         res = {"dt": dt, "its": steps / dt, "steps": steps, "kern": kern, "sweep_ms": kern[sweep_name],
+               "block_ms_per_step": [d / steps * 1e3 for d in dts],
                "sweep_bytes": sweep_words * 4 * f.k.N,
                "iter_words": sweep_words + (3 if a.no_defer else 0) + (0 if fact else 2),   # + dfx_axpy, + dfx_bcast
-               "launches": len(timing[sweep_name]) // steps, "zc": f.k.plan.zc, "n_local": f.k.N,
-               "pair_probe": getattr(f.k, "pair_probe", None),
+               "launches": len(timing[sweep_name]) // (steps * len(dts)), "zc": f.k.plan.zc, "n_local": f.k.N,
+               "pair_probe": getattr(f.k, "pair_probe", None), "placement": getattr(f.k, "placement_info", None),
                "plan": {k: getattr(f.k.plan, k) for k in ("fast", "zc", "n_zchunks", "steps", "n_chunks", "cpb", "n_blocks")}}
         if sharded:
             # what the compute stream spent waiting for collectives, per iteration (this rank): the all-reduce of the
@@ -328,6 +405,11 @@ def main():
         except (OSError, KeyError, ValueError) as e:
             return None, f"none: {type(e).__name__} reading profiles/{PMC_RECORD}"
 
+    # DFX_BENCH_STRONG=1 (with DFX_FORCE_COMM=1): rehearse the strong-scaling leg with one rank on a 1-GPU box
+    want_strong = group is not None and a.workload == "c2" and (world > 1 or os.environ.get("DFX_BENCH_STRONG") == "1")
+    # the strong-scaled configs[2] leg first: it is the measurement north_star's scaling target is about, and its
+    # one-GPU anchor wants the memory before anything else has used it
+    strong = strong_scaling_leg(a, world, rank, dev, group, run, roofline) if want_strong else None
     main_res = run(a.residual)
     other = "explicit" if a.residual == "factored" else "factored"
     # the explicit residual needs a third resident 5-D vector: skip that leg where it cannot fit (configs 3 / 4 whole
@@ -335,9 +417,6 @@ def main():
     n_vec = 3 if other == "explicit" else 2
     fits = n_vec * 4 * main_res["n_local"] < 0.93 * torch.cuda.mem_get_info()[1]
     other_res = None if (a.single or not fits) else run(other)
-    # DFX_BENCH_STRONG=1 (with DFX_FORCE_COMM=1): rehearse the strong-scaling leg with one rank on a 1-GPU box
-    want_strong = group is not None and a.workload == "c2" and (world > 1 or os.environ.get("DFX_BENCH_STRONG") == "1")
-    strong = strong_scaling_leg(a, world, rank, dev, group, run, roofline) if want_strong else None
     n_local = main_res["n_local"]
     n_total = n_local * world
     its, dt = main_res["its"], main_res["dt"]
@@ -348,6 +427,9 @@ def main():
         "value": its * world, "unit": "it/s", "iters_per_s": its, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        # `repeats` timed blocks of exactly `steps` iterations each; value / ms_per_step are the MEDIAN block's
+        "timed_blocks": {"repeats": len(main_res["block_ms_per_step"]), "ms_per_step": main_res["block_ms_per_step"],
+                         "min": min(main_res["block_ms_per_step"]), "max": max(main_res["block_ms_per_step"])},
         "config": {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r}, tol=None, baseline init "
                                f"({a.workload}; {nz_gpu} z-planes per GPU)", "n_elements": n_total,
                    "parallelism": f"z-shard x{world}",
@@ -356,7 +438,7 @@ def main():
                                        "sharded volume", "x_update": "textbook" if a.no_defer else "deferred",
                    "residual": a.residual, "words_moved_per_iteration": f"{main_res['iter_words']} N",
                    "sweep_launches_per_iteration": main_res["launches"], "plan": main_res["plan"],
-                   "placement_probe_GBps": main_res["pair_probe"]},
+                   "placement_probe_GBps": main_res["pair_probe"], "placement": main_res["placement"]},
         # whole iteration, all GPUs: SURVEY 8(d) prices an iteration at 32 N bytes and asks for that basis to be quoted
         # as "effective"; the build moves fewer (16 N with the factored residual), so "effective" may exceed the peak:
         # the honest bandwidth figure is hbm_moved_GBps and the per-kernel roofline below

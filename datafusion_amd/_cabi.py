@@ -52,6 +52,8 @@ SIGNATURES = {
     "dfx_bcast": [_G, _PL, _P, _P, _P, _P, _P, _f, _f, _f, _P, _P, _P, _P],
     "dfx_adam_step": [_G, _PL, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _i32, _i32, _P, _P, _P, _P, _P],
     "dfx_adam_step_factored": [_G, _PL, _P, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _i32, _i32, _P, _P, _P, _P, _P],
+    "dfx_adam_step_chunks": [_G, _PL, _P, _P, _P, _P, _P, _P, _P, _P, _d, _d, _d, _d, _i32, _i32, _P, _P, _P, _P,
+                             _i32, _i32, _i32, _P],
     "dfx_lerp": [_P, _P, _i64, _d, _P],
     "dfx_adam_apply": [_P, _P, _P, _P, _i64, _d, _d, _d, _d, _i32, _i32, _i32, _P, _P, _P],
     "dfx_adam_prep": [_P, _P, _P, _P, _P, _i64, _P, _P, _P, _i64, _P, _P, _i64, _d, _d, _d, _P, _P, _P],
@@ -79,6 +81,14 @@ SIGNATURES = {
     "dfx_block_expand": [_P, _P, _i64, _i64, _i64, _i32, _f, _P],
     "dfx_baseline_init": [_G, _P, _P, _P, _f, _P, _P, _P, _P],
     "dfx_resize_stack": [_P, _P, _P, _P, _i64, _i64, _i64, _i64, _i64, _i32, _P],
+    "dfx_arena_create": [_i64, _i64, C.POINTER(_P)],
+    "dfx_arena_grow": [_P, _i64],
+    "dfx_arena_info": [_P, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)],
+    "dfx_arena_map": [_P, C.POINTER(_i32), _i64, C.POINTER(_P)],
+    "dfx_arena_unmap": [_P, _P],
+    "dfx_arena_release_chunks": [_P, C.POINTER(_i32), _i64],
+    "dfx_arena_destroy": [_P],
+    "dfx_arena_last_error": [],
 }
 
 _lib = None
@@ -100,13 +110,13 @@ def lib() -> C.CDLL:
         for name, args in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = args
-            fn.restype = C.c_char_p if name == "dfx_last_error" else C.c_int
+            fn.restype = C.c_char_p if name in ("dfx_last_error", "dfx_arena_last_error") else C.c_int
     return _lib
 
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        msg = lib().dfx_last_error()
+        msg = lib().dfx_arena_last_error() if what.startswith("dfx_arena") else lib().dfx_last_error()
         raise DfxError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 

@@ -528,6 +528,8 @@ struct AdamArgs {
     int non_neg;
     Geo q;
     int steps, cpb;
+    int c_lo, c_hi;   // chunk range of THIS launch (a full step is [0, cpb)), as in SweepArgs
+    int row0;         // first row of `part` this launch writes
 };
 
 template <bool M1F>
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
                 if (M1F) m1av[k] = ld4(a.m1a + off + (long long)k * a.q.P);
             }
         }
-        for (int c = 0; c < a.cpb; ++c) {
+        for (int c = a.c_lo; c < a.c_hi; ++c) {
             const int m0 = c * a.steps * gz + bz;
             const int m1e = min((c + 1) * a.steps * gz, a.q.M);
             f4 uacc[ZC];
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
         }
     }
     const long long bid = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    block_store3(ddd, dxx, 0.0, a.part + bid * DFX_NPART);
+    block_store3(ddd, dxx, 0.0, a.part + (a.row0 + bid) * DFX_NPART);
 }
 
 // torch.optim.Adam's step on an EXPLICIT gradient (the autograd formulation, fusion.py:338-342: loss.backward() has
@@ -902,12 +904,15 @@ __global__ __launch_bounds__(256) void k_reduce1(const float *a, const float *b,
 }
 
 // dst[k] = scale * sum_rows parts[row*DFX_NPART + k], k < nvals <= 3; one workgroup; fixed order.
+// tol_dst != NULL (the Adam steps): *tol_dst = sqrt(r[0] / r[1]) = ||x - prev_x|| / ||x||, fusion.py:244-252,348.
 __global__ __launch_bounds__(256) void k_fold(const double *parts, int n_rows, int nvals, double *dst,
-                                              double scale) {
+                                              double scale, double *tol_dst) {
     double r[3];
     fold_cols<3>(parts, n_rows, r);     // rows always hold three values (block_store3): unused columns cost nothing
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         for (int k = 0; k < nvals; ++k) dst[k] = scale * r[k];
+        if (tol_dst) *tol_dst = sqrt(r[0] / r[1]);
+    }
 }
 
 __device__ __forceinline__ void cg_alpha_body(double *s, double c1, double c2, double eps) {
@@ -1024,6 +1029,7 @@ __global__ __launch_bounds__(256) void k_post_fold(const PostArgs a) {
     if (a.flags & DFX_POST_FOLD_ADAM) {
         s[DFX_S_ADAM_DD] = rows[0];
         s[DFX_S_ADAM_XX] = rows[1];
+        s[DFX_S_TOL] = sqrt(rows[0] / rows[1]);   // fusion.py:244-252 as FusionAdam uses it (fusion.py:348); one shard's view
     }
     if (a.flags & DFX_POST_ALPHA) cg_alpha_body(s, a.c1, a.c2, a.eps);
 }
@@ -1331,8 +1337,9 @@ __global__ __launch_bounds__(256) void k_block_expand(const float *in, float *ou
 // ------------------------------------------------------------------------------------------
 // Input stage (utils.py:411-427 load_data): skimage.transform.resize(cmos, (S1, S2, nZ)) with its defaults, restated
 // per (x, y) plane of a float64 stack: Gaussian pre-filter (scipy.ndimage.gaussian_filter: separable, truncate 4,
-// mode "reflect" = half-sample symmetric) on the axes that shrink, then order-1 interpolation at the centres of the
-// output grid (scipy.ndimage.zoom(order=1, mode="reflect", grid_mode=True)).  PARITY UNPINNED against scikit-image
+// mode "mirror" = whole-sample symmetric, which is what skimage translates its default mode "reflect" to) on the axes
+// that shrink, then order-1 interpolation at the centres of the output grid
+// (scipy.ndimage.zoom(order=1, mode="mirror", grid_mode=True)).  PARITY UNPINNED against scikit-image
 // itself (absent from the image); checked against the scipy calls it is built from.
 // ------------------------------------------------------------------------------------------
 #define DFX_RESIZE_MAXR 64
@@ -1344,8 +1351,11 @@ struct GaussArgs {
     double w[DFX_RESIZE_MAXR + 1];   // w[k], k = 0..radius (symmetric kernel, normalised)
 };
 
-__device__ __forceinline__ int reflect_idx(int i, int n) {   // d c b a | a b c d | d c b a
-    while (i < 0 || i >= n) i = i < 0 ? -i - 1 : 2 * n - i - 1;
+// skimage's resize hands its default mode "reflect" (numpy.pad's name) to scipy.ndimage as "mirror"
+// (skimage/_shared/utils.py: _to_ndimage_mode): whole-sample symmetric, the edge sample is NOT repeated.
+__device__ __forceinline__ int reflect_idx(int i, int n) {   // d c b | a b c d | c b a
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
     return i;
 }
 
@@ -1561,8 +1571,9 @@ int noalloc_scratch(hipStream_t st, double **out) {
     return 0;
 }
 
-int fold(const double *parts, int n_rows, int nvals, double *dst, double scale, hipStream_t st) {
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, st, parts, n_rows, nvals, dst, scale);
+int fold(const double *parts, int n_rows, int nvals, double *dst, double scale, hipStream_t st,
+         double *tol_dst = nullptr) {
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, st, parts, n_rows, nvals, dst, scale, tol_dst);
     DFX_LAUNCH_CHECK("fold");
     return 0;
 }
@@ -1849,11 +1860,17 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
 static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, const float *m1a, const float *m1b,
                      float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
                      double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
-                     float *v_part, double *part, void *stream) {
+                     float *v_part, double *part, int32_t c_lo, int32_t c_hi, int32_t slice, void *stream) {
     Geo q;
     if (int rc = make_geo(g, &q)) return rc;
     if (int rc = check_plan(q, pl)) return rc;
     q.zs = pl->fast ? pl->zs : 1;
+    if (c_hi < 0) c_hi = pl->cpb;       // the whole-volume entry points
+    if (c_lo < 0 || c_hi > pl->cpb || c_lo >= c_hi || slice < 0 || slice >= DFX_MAX_SLICES)
+        return fail(DFX_EINVAL, "dfx_adam_step_chunks: need 0 <= c_lo < c_hi <= cpb and 0 <= slice < DFX_MAX_SLICES");
+    if (!pl->fast && (c_lo != 0 || c_hi != pl->cpb || slice != 0))
+        return fail(DFX_EINVAL, "dfx_adam_step_chunks: the generic path steps whole volumes only");
+    const bool last_slice = (c_hi == pl->cpb);
     const bool m1f = (m1 == nullptr);
     if (!x || !m2 || !A || !B || !scal || !u_part || !v_part || !part || (m1f && (!m1a || !m1b)))
         return fail(DFX_EINVAL, "dfx_adam_step: NULL buffer");
@@ -1863,7 +1880,8 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     AdamArgs a{x, m1, m2, m1a, m1b, A, B, mask, u_part, v_part, part, (float)beta1, (float)beta2,
                (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-               (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (non_neg & DFX_ADAM_NONNEG) ? 1 : 0, q, pl->steps, pl->cpb};
+               (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (non_neg & DFX_ADAM_NONNEG) ? 1 : 0, q, pl->steps, pl->cpb,
+               c_lo, c_hi, slice * pl->n_blocks};
     int n_rows;
     if (pl->fast) {
         if (!aligned16(x) || !aligned16(m1) || !aligned16(m2) || !aligned16(A) || !aligned16(mask) ||
@@ -1882,7 +1900,7 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
         else
             DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false, false>), grid, block, 0, st, a));
         DFX_LAUNCH_CHECK("dfx_adam_step(fast)");
-        n_rows = pl->n_blocks;
+        n_rows = (slice + 1) * pl->n_blocks;
     } else {
         n_rows = pl->n_blocks;
         hipLaunchKernelGGL(k_gen_adam, dim3(n_rows), dim3(256), 0, st, a);
@@ -1893,8 +1911,9 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
                            v_part, q);
         DFX_LAUNCH_CHECK("dfx_adam_step(generic v)");
     }
-    if (non_neg & DFX_ADAM_NOFOLD) return 0;   // the rows are left for dfx_post_sweep(DFX_POST_FOLD_ADAM)
-    return fold(part, n_rows, 2, scal + DFX_S_ADAM_DD, 1.0, st);   // (DD, XX) -> consecutive slots
+    // the rows are left for dfx_post_sweep(DFX_POST_FOLD_ADAM), or this is not the final slice
+    if ((non_neg & DFX_ADAM_NOFOLD) || !last_slice) return 0;
+    return fold(part, n_rows, 2, scal + DFX_S_ADAM_DD, 1.0, st, scal + DFX_S_TOL);   // (DD, XX) -> consecutive slots, TOL
 }
 
 int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, float *m2, const float *A,
@@ -1902,7 +1921,18 @@ int dfx_adam_step(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, fl
                   int32_t non_neg, double *scal, float *u_part, float *v_part, double *part, void *stream) {
     if (!m1) return fail(DFX_EINVAL, "dfx_adam_step: NULL buffer");
     return adam_impl(g, pl, x, m1, nullptr, nullptr, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, scal, u_part,
-                     v_part, part, stream);
+                     v_part, part, 0, -1, 0, stream);
+}
+
+int dfx_adam_step_chunks(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, const float *m1a, const float *m1b,
+                         float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
+                         double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
+                         float *v_part, double *part, int32_t c_lo, int32_t c_hi, int32_t slice, void *stream) {
+    if ((m1 != nullptr) == (m1a != nullptr || m1b != nullptr) || ((m1a == nullptr) != (m1b == nullptr)))
+        return fail(DFX_EINVAL, "dfx_adam_step_chunks: pass either m1 or both m1a and m1b");
+    if (c_hi < 0) return fail(DFX_EINVAL, "dfx_adam_step_chunks: need 0 <= c_lo < c_hi <= cpb");
+    return adam_impl(g, pl, x, m1, m1a, m1b, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, scal, u_part, v_part,
+                     part, c_lo, c_hi, slice, stream);
 }
 
 int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, const float *m1a, const float *m1b,
@@ -1911,7 +1941,7 @@ int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, cons
                            float *v_part, double *part, void *stream) {
     if (!m1a || !m1b) return fail(DFX_EINVAL, "dfx_adam_step_factored: NULL buffer");
     return adam_impl(g, pl, x, nullptr, m1a, m1b, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, scal, u_part,
-                     v_part, part, stream);
+                     v_part, part, 0, -1, 0, stream);
 }
 
 int dfx_adam_apply(float *x, const float *grad, float *m1, float *m2, int64_t n, double lr, double beta1,
@@ -1943,7 +1973,7 @@ int dfx_adam_apply(float *x, const float *grad, float *m1, float *m2, int64_t n,
     if (nb > DFX_EW_MAXBLOCKS) nb = DFX_EW_MAXBLOCKS;
     hipLaunchKernelGGL(k_adam_apply<DFX_APPLY_UNROLL>, dim3(nb), dim3(256), 0, st, x, grad, m1, m2, (long long)n, a);
     DFX_LAUNCH_CHECK("dfx_adam_apply");
-    return fold(part, nb, 2, scal + DFX_S_ADAM_DD, 1.0, st);
+    return fold(part, nb, 2, scal + DFX_S_ADAM_DD, 1.0, st, scal + DFX_S_TOL);
 }
 
 int dfx_adam_prep(const float *u, const float *cmos, const float *cmask, float *A, float *m1a, int64_t n_u,

@@ -79,7 +79,7 @@ class Fusion:
     def __init__(self, spc, cmos, *, weights: dict, init_type: str, tol: float | None = 3e-3,
                  mask_noise: bool = False, total_energy: float = 1.0, device: str = "cuda", seed: int = 42,
                  verbose: bool = False, group=None, defer_x: bool = True, target_blocks: int = 0,
-                 placement_tries: int = 6):
+                 placement_tries: int = 6, comm_slices: int | str = "auto", placement: str = "rank"):
         dev = torch.device(device)
         self.spc = self._to_device(spc, "spc", dev)      # fusion.py:135-148
         self.cmos = self._to_device(cmos, "cmos", dev)
@@ -102,6 +102,13 @@ class Fusion:
             raise ValueError("cmos (z, x, y) must be an integer multiple r of spc (t, l, x/r, y/r) in x and y")
         self.defer_x = bool(defer_x) and not verbose
         self.placement_tries = int(placement_tries)   # HipKernels.new_vector_paired: large vectors only
+        # launches a z-sharded 5-D pass is cut into so that the all-reduce of v overlaps it.  "auto": decided at the
+        # start of a solve from one timed all-reduce of v; a number: that many launches (1 = one all-reduce after the
+        # whole pass, no overlap - the setting to rule the asynchronous path out with)
+        self._comm_slices_arg = comm_slices if comm_slices == "auto" else int(comm_slices)
+        self.comm_slices = 1 if comm_slices == "auto" else int(comm_slices)
+        self.comm_probe = None
+        self.comm_timing = None   # bench.py: dict name -> list of (start, end) events around the waits for collectives
 
         self.T = SumOperator(size=self.n_times, integral_dim=0)        # fusion.py:172-179
         self.S = SumOperator(size=self.n_lambdas, integral_dim=1)
@@ -124,6 +131,14 @@ class Fusion:
 
         self.k = self._backend_cls(self.n_times, self.n_lambdas, z1 - z0, self.x_shape[3], self.x_shape[4], r, dev,
                                    target_blocks)
+        # placement of the 5-D vectors in device memory: "rank" (default) lays out all vectors of a solve together by
+        # measured memory class when they are >= 8 GiB each (placement.py); "probe": the second vector is chosen among
+        # up to placement_tries torch allocations by timing (round 1 - 2 behaviour); "plain": torch allocations as they come
+        if placement not in ("rank", "probe", "plain"):
+            raise ValueError("placement must be 'rank', 'probe' or 'plain'")
+        if placement == "plain":
+            self.placement_tries = 1
+        self.k.reserve_vectors(self._n_volumes(), placement)
         self._cmos_loc = self.cmos[z0:z1].contiguous()
         self._cmask_loc = self.cmos_mask[z0:z1].float().contiguous()
         self._smask_f = self.spc_mask.float().contiguous()
@@ -154,6 +169,10 @@ class Fusion:
                                   antialias=False).squeeze(0)
         return any_z.bool(), cmos_mask
 
+    def _n_volumes(self) -> int:
+        """5-D vectors this solver sweeps in lock-step (x included); 0: not known here."""
+        return 0
+
     def _initialize(self) -> torch.Tensor:
         """fusion.py:254-272 + the masking / normalisation of fusion.py:197-199, on the device."""
         k, z0, z1 = self.k, *self.z_range
@@ -175,10 +194,11 @@ class Fusion:
             torch.manual_seed(self.seed)
             lo, hi = self.cmos.min().cpu(), self.cmos.max().cpu()
             full = (lo - hi) * torch.rand(self.x_shape) + hi
-            x = full[:, :, z0:z1].contiguous().to(k.device)
+            x = k.new_vector()
+            x.copy_(full[:, :, z0:z1])
         elif self.init_type == "zeros":
             torch.manual_seed(self.seed)
-            x = torch.zeros(self.local_shape, dtype=torch.float32, device=k.device)
+            x = k.new_vector().zero_()
         else:
             raise ValueError("Invalid initialization type.")                 # fusion.py:271
         if self.mask_noise:
@@ -201,6 +221,45 @@ class Fusion:
         k.sqdiff(self.spc, k.v, self._smask_f if self.mask_noise else None, w2, cabi.S_LOSS2)
         self.comm.sum_(k.scal[cabi.S_LOSS1:cabi.S_LOSS1 + 1])
         return k.scal[cabi.S_LOSS1].float(), k.scal[cabi.S_LOSS2].float()
+
+    SLICE_LAUNCH_COST_S = 50e-6   # measured, one-rank RCCL group at C2: 2.81 / 2.86 / 2.96 / 3.15 ms per iteration
+                                  # for 1 / 2 / 4 / 8 launches (kernel tail + relaunch, the band's dfx_reduce_v, hand-over)
+
+    def _auto_slices(self) -> int:
+        """How many launches to cut a sharded sweep into.  Every band's all-reduce but the last hides behind the
+        bands still being swept; bands shrink linearly (HipKernels._slice_bounds), so with k launches the exposed
+        one carries 2/(k(k+1)) of v.  Each extra launch costs ~50 us on an MI355X.  The all-reduce is priced from a
+        MEASUREMENT on this group, taken here: one all-reduce of the v buffer and one of 8 floats (latency), max over
+        ranks -> T(bytes) = lat + bytes / bw.  Every rank computes the same k from the same two numbers."""
+        if self.comm.size <= 1 and not self.comm._always:
+            return 1
+        if self._comm_slices_arg != "auto":
+            return int(self._comm_slices_arg)
+        if self.comm_probe is not None:
+            return self.comm_probe["slices"]
+        t_full, t_lat = self.comm.measure_allreduce(self.k.v)
+        nbytes = 4.0 * self.k.v.numel()
+        bw = nbytes / max(t_full - t_lat, 1e-7)
+        cost = {k: t_lat + nbytes * 2.0 / (k * (k + 1)) / bw + self.SLICE_LAUNCH_COST_S * (k - 1)
+                for k in range(1, cabi.MAX_SLICES + 1)}
+        best = min(cost, key=cost.get)
+        self.comm_probe = {"v_bytes": int(nbytes), "allreduce_v_s": t_full, "allreduce_8_floats_s": t_lat,
+                           "busbw_GBps": nbytes / max(t_full - t_lat, 1e-7) / 1e9, "slices": best,
+                           "modelled_exposed_s": cost[best]}
+        return best
+
+    def _comm_timed(self, name, fn):
+        """Run `fn` (which makes the compute stream wait for collectives); when comm_timing is set, bracket it with
+        events on the compute stream: their distance is the time the stream stood still, i.e. exposed communication."""
+        if self.comm_timing is None:
+            return fn()
+        st = torch.cuda.current_stream(self.k.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        out = fn()
+        e1.record(st)
+        self.comm_timing.setdefault(name, []).append((e0, e1))
+        return out
 
     def _save_solver_state(self):
         """Hook for solvers whose loop keeps live state in k.u / k.v / scal (FusionCG): called before a projection of
@@ -256,61 +315,20 @@ class Fusion:
 class FusionCG(Fusion):
     """Conjugate gradient on the normal equations (fusion.py:389-496)."""
 
-    def __init__(self, *args, comm_slices: int | str = "auto", residual: str = "factored", **kwargs):
+    def __init__(self, *args, residual: str = "factored", **kwargs):
         """residual="factored" (default): r = b - A x is kept as the two small arrays it is made of,
         r = ra[z,x,y] + rb[t,l,x/r,y/r] (include/dfx.h, dfx_resid_update) - one 4N-word pass per iteration and
         two resident 5-D vectors (x, p).  residual="explicit": r is a third 5-D vector updated by dfx_bcast
         (2N words) and read by the sweep (5N words), the literal transcription of fusion.py:446."""
         if residual not in ("factored", "explicit"):
             raise ValueError("residual must be 'factored' or 'explicit'")
-        super().__init__(*args, **kwargs)
         self.residual = residual
+        super().__init__(*args, **kwargs)
         self.w1 = self.weights["spatial"]
         self.w2 = self.weights["spectro_temporal"]
         self._r = self._p = None
-        # "auto": decided in start() from one timed all-reduce of v; a number: that many launches (1 = one all-reduce
-        # after the whole sweep, no overlap - the setting to rule the asynchronous path out with)
-        self._comm_slices_arg = comm_slices if comm_slices == "auto" else int(comm_slices)
-        self.comm_slices = 1 if comm_slices == "auto" else int(comm_slices)
-        self.comm_probe = None
-        self.comm_timing = None   # bench.py: dict name -> list of (start, end) events around the waits for collectives
         self._pending_x = False
         self._stopped = False
-
-    SLICE_LAUNCH_COST_S = 50e-6   # measured, one-rank RCCL group at C2: 2.81 / 2.86 / 2.96 / 3.15 ms per iteration
-                                  # for 1 / 2 / 4 / 8 launches (kernel tail + relaunch, the band's dfx_reduce_v, hand-over)
-
-    def _auto_slices(self) -> int:
-        """How many launches to cut a sharded sweep into.  Every band's all-reduce but the last hides behind the
-        bands still being swept; bands shrink linearly (HipKernels._slice_bounds), so with k launches the exposed
-        one carries 2/(k(k+1)) of v.  Each extra launch costs ~50 us on an MI355X.  The all-reduce is priced from a
-        MEASUREMENT on this group, taken here: one all-reduce of the v buffer and one of 8 floats (latency), max over
-        ranks -> T(bytes) = lat + bytes / bw.  Every rank computes the same k from the same two numbers."""
-        if self.comm.size <= 1 and not self.comm._always:
-            return 1
-        t_full, t_lat = self.comm.measure_allreduce(self.k.v)
-        nbytes = 4.0 * self.k.v.numel()
-        bw = nbytes / max(t_full - t_lat, 1e-7)
-        cost = {k: t_lat + nbytes * 2.0 / (k * (k + 1)) / bw + self.SLICE_LAUNCH_COST_S * (k - 1)
-                for k in range(1, cabi.MAX_SLICES + 1)}
-        best = min(cost, key=cost.get)
-        self.comm_probe = {"v_bytes": int(nbytes), "allreduce_v_s": t_full, "allreduce_8_floats_s": t_lat,
-                           "busbw_GBps": nbytes / max(t_full - t_lat, 1e-7) / 1e9, "slices": best,
-                           "modelled_exposed_s": cost[best]}
-        return best
-
-    def _comm_timed(self, name, fn):
-        """Run `fn` (which makes the compute stream wait for collectives); when comm_timing is set, bracket it with
-        events on the compute stream: their distance is the time the stream stood still, i.e. exposed communication."""
-        if self.comm_timing is None:
-            return fn()
-        st = torch.cuda.current_stream(self.k.device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        out = fn()
-        e1.record(st)
-        self.comm_timing.setdefault(name, []).append((e0, e1))
-        return out
 
     def _save_solver_state(self):
         """loss() / marginals() project x into k.u, k.v and overwrite UU, PP, XX, XP - which, between two iterate()
@@ -328,6 +346,9 @@ class FusionCG(Fusion):
         if saved is not None:
             k = self.k
             k.u.copy_(saved[0]), k.v.copy_(saved[1]), k.scal[cabi.S_UU:cabi.S_XP + 1].copy_(saved[2])
+
+    def _n_volumes(self) -> int:
+        return 2 if self.residual == "factored" else 3      # x, p (, r)
 
     def _sweep(self, mode, eps: float | None = None) -> None:
         """One pass over x, (r,) p and everything that follows it: u(p), v(p), UU, VV, PP, XX, XP - and, when `eps` is
@@ -395,8 +416,7 @@ class FusionCG(Fusion):
         k, c = self.k, self.comm
         c1, c2 = self._coefs()
         fact = self.residual == "factored"
-        if self._comm_slices_arg == "auto" and self.comm_probe is None and (c.size > 1 or c._always):
-            self.comm_slices = self._auto_slices()          # k.v is scratch here: it is overwritten by the projection below
+        self.comm_slices = self._auto_slices()              # k.v is scratch here: it is overwritten by the projection below
         if self._p is None:
             self._p = k.new_vector_paired(self.x, self._placement_tries(planned_iterations))
             if fact:
@@ -428,6 +448,11 @@ class FusionCG(Fusion):
         x, rv, pv = self.x, self._r, self._p
         deferred = self.defer_x
         one_gpu = not (c.size > 1 or c._always)
+        if self._stopped or int(n_iterations) <= 0:
+            # the loop was left through the tolerance test (fusion.py:451-453): RSOLD is already the new residual but
+            # UU, VV still belong to the old p (the sweep was skipped), so ALPHA - which finish() may still owe to x -
+            # must not be recomputed.  A stopped solve stays stopped until start() is called again.
+            return
         # alpha of the first iteration of this call; every later one is computed by the launch that follows the sweep
         k.cg_alpha(c1, c2, eps)                                                 # fusion.py:443-444
         if history is not None and deferred:
@@ -531,12 +556,27 @@ class FusionAdam(Fusion):
         moment1="explicit": exp_avg is a 5-D vector as in torch.optim.Adam (6N words)."""
         if moment1 not in ("factored", "explicit"):
             raise ValueError("moment1 must be 'factored' or 'explicit'")
-        super().__init__(*args, **kwargs)
         self.fused = fused
         self.moment1 = moment1
+        super().__init__(*args, **kwargs)
         self.betas, self.adam_eps = betas, adam_eps
         self._m1 = self._m2 = self._m1a = self._m1b = self._gA = self._gB = None
         self._adam_step = 0
+        self._last_norms = None
+
+    def tolerance(self) -> torch.Tensor:
+        """fusion.py:244-252 as FusionAdam uses it (fusion.py:348): ||x - prev_x|| / ||x|| of the last step; prev_x is
+        never materialised, the two squared norms come out of the step's own pass.  Summed over shards: with a
+        process group every rank must call it (it is a collective).  Before the first step: 0."""
+        if self._last_norms is None:
+            return super().tolerance()
+        d = self._last_norms.clone()
+        self.comm.sum_(d)
+        return torch.sqrt(d[0] / d[1]).float()
+
+    def _n_volumes(self) -> int:
+        # fused: x, exp_avg_sq (, exp_avg); the autograd formulation allocates its gradient per backward(): not planned
+        return (2 if self.moment1 == "factored" else 3) if self.fused else 0
 
     def loss_autograd(self, mask_grad: bool = False):
         return _FusionLossFn.apply(self.x, self, mask_grad)
@@ -561,19 +601,21 @@ class FusionAdam(Fusion):
         if self._m2 is None:                       # buffers are kept for later calls (state is reset below)
             big = 4 * k.N >= (8 << 30)      # the sweep-based probe did not help Adam below that (C2: 331 vs 331 it/s)
             self._m2 = k.new_vector_paired(x, self.placement_tries if big and max_iterations >= 30 else 1)
-            self._m1 = None if fact else torch.empty_like(x)
+            self._m1 = None if fact else k.new_vector()
             self._m1a = torch.empty_like(k.u) if fact else None
             self._m1b = torch.empty_like(k.v) if fact else None
         for t in (self._m1, self._m1a, self._m1b, self._m2):
             if t is not None:
                 t.zero_()
         self._adam_step = 0
+        self.comm_slices = self._auto_slices()             # k.v is scratch here: the projection below overwrites it
         self._project(x)                                   # u(x), v(x) for the first loss / gradient
         cmask = self._cmask_loc if self.mask_noise else None
         smask = self._smask_f if self.mask_noise else None
         if self._gA is None:
             self._gA, self._gB = torch.empty_like(k.u), torch.empty_like(k.v)
         A, B = self._gA, self._gB
+        sharded = c.size > 1 or c._always
         for i in range(max_iterations):
             self.curr_iter += 1
             self._adam_step += 1
@@ -585,15 +627,24 @@ class FusionAdam(Fusion):
                 c.sum_(k.scal[cabi.S_LOSS1:cabi.S_LOSS1 + 1])                   # the cmos term is a sum over shards
                 l1, l2 = k.scal[cabi.S_LOSS1].float(), k.scal[cabi.S_LOSS2].float()
             # one 5-D pass (mask: fusion.py:274-278), then dfx_post_sweep for u(x), v(x), ||dx||^2, ||x||^2
-            k.adam_step(x, self._m1, self._m2, A, B, cmask, lr, self.betas[0], self.betas[1], self.adam_eps,
-                        self._adam_step, non_neg, m1a=self._m1a, m1b=self._m1b, fold=False)
-            k.post_sweep(cabi.POST_U | cabi.POST_V | cabi.POST_FOLD_ADAM)
-            c.sum_(k.v)
+            if sharded:
+                # as FusionCG._sweep: the pass is cut into comm_slices launches and the all-reduce of each finished
+                # band of v(x) (the RD partials of the next iteration's loss) runs on RCCL's stream under the bands
+                # still being stepped; only the last, shortest band's is exposed
+                pending = []
+                k.adam_step(x, self._m1, self._m2, A, B, cmask, lr, self.betas[0], self.betas[1], self.adam_eps,
+                            self._adam_step, non_neg, m1a=self._m1a, m1b=self._m1b, fold=False,
+                            slices=self.comm_slices, after_slice=lambda rows: pending.append(c.sum_async(rows)))
+                k.post_sweep(cabi.POST_U | cabi.POST_FOLD_ADAM)
+                c.wait(pending)
+            else:
+                k.adam_step(x, self._m1, self._m2, A, B, cmask, lr, self.betas[0], self.betas[1], self.adam_eps,
+                            self._adam_step, non_neg, m1a=self._m1a, m1b=self._m1b, fold=False)
+                k.post_sweep(cabi.POST_U | cabi.POST_V | cabi.POST_FOLD_ADAM)
+            self._last_norms = k.scal[cabi.S_ADAM_DD:cabi.S_ADAM_XX + 1]        # this shard's ||dx||^2, ||x||^2
             tolerance = None
             if self.tol is not None:                                            # fusion.py:348
-                d = k.scal[cabi.S_ADAM_DD:cabi.S_ADAM_XX + 1].clone()
-                c.sum_(d)
-                tolerance = float(torch.sqrt(d[0] / d[1]))
+                tolerance = float(self.tolerance())
             if tolerance is not None and tolerance < self.tol:                  # fusion.py:357-358
                 break
             if history is not None:
@@ -612,11 +663,10 @@ class FusionAdam(Fusion):
             loss = spatial_loss + spectro_temporal_loss
             loss.backward()
             optimizer.step()                                                    # + clamp (fusion.py:344-346)
+            self._last_norms = optimizer.last_sq_norms                          # ||x - prev_x||^2, ||x||^2 (this shard)
             tolerance = None
             if self.tol is not None:                                            # fusion.py:348
-                d = optimizer.last_sq_norms.clone()                             # ||x - prev_x||^2, ||x||^2
-                self.comm.sum_(d)
-                tolerance = float(torch.sqrt(d[0] / d[1]))
+                tolerance = float(self.tolerance())
             if tolerance is not None and tolerance < self.tol:
                 break
             if history is not None:

@@ -4,7 +4,10 @@ The reference resizes the CMOS stack with `skimage.transform.resize(cmos_xyz, (S
 order 1, mode "reflect", anti-aliasing on when shrinking).  scikit-image is not part of this image, so
 its published algorithm (skimage >= 0.19, `transform/_warps.py: resize`) is restated: a Gaussian pre-filter with
 sigma = (factor - 1) / 2 per shrunk axis, then order-1 interpolation at the output grid's cell centres
-(`ndimage.zoom(order=1, mode="reflect", grid_mode=True)`).
+(`ndimage.zoom(order=1, grid_mode=True)`), both with scipy's mode "mirror" - skimage's mode names are numpy.pad's and
+its `_to_ndimage_mode` translates the default "reflect" (d c b | a b c d, edge not repeated) to ndimage's "mirror".
+Integer stacks are rescaled like skimage's `img_as_float` (unsigned: / dtype max; signed: onto [-1, 1]; bool: 0 / 1)
+before resizing, as `resize(preserve_range=False)` does.
   * `device=` given: the stack is resized ON THE GPU by dfx_resize_stack (hand-written kernels, float64), so the
     README flow needs neither scikit-image nor a host pass over the full-resolution acquisition;
   * `device=None`: the same restatement over scipy.ndimage on the host (the checker of the device path in the tests).
@@ -19,20 +22,36 @@ from __future__ import annotations
 import numpy as np
 
 
+def as_float_like_skimage(image) -> np.ndarray:
+    """skimage.util.img_as_float as resize(preserve_range=False) applies it: floats pass through (as float64 here),
+    unsigned integers are divided by their dtype's maximum, signed ones mapped onto [-1, 1], bool becomes 0 / 1."""
+    a = np.asarray(image)
+    if a.dtype.kind == "f":
+        return a.astype(np.float64)
+    if a.dtype.kind == "b":
+        return a.astype(np.float64)
+    if a.dtype.kind == "u":
+        return a.astype(np.float64) / float(np.iinfo(a.dtype).max)
+    if a.dtype.kind == "i":
+        lo, hi = float(np.iinfo(a.dtype).min), float(np.iinfo(a.dtype).max)
+        return (a.astype(np.float64) - lo) / (hi - lo) * 2.0 - 1.0
+    raise TypeError(f"unsupported image dtype {a.dtype}")
+
+
 def resize_like_skimage(image: np.ndarray, output_shape) -> np.ndarray:
     """skimage.transform.resize(image, output_shape) with its defaults, for float images (host, scipy.ndimage)."""
     from scipy import ndimage as ndi
     out_dtype = np.float32 if np.asarray(image).dtype == np.float32 else np.float64
-    image = np.asarray(image, dtype=np.float64)
+    image = as_float_like_skimage(image)
     output_shape = tuple(int(s) for s in output_shape)
     if image.ndim != len(output_shape):
         raise ValueError("output_shape must have one entry per image axis")
     factors = np.divide(image.shape, output_shape)
     if np.any(factors > 1):  # anti_aliasing defaults to True when down-sampling
         sigma = np.maximum(0, (factors - 1) / 2)
-        image = ndi.gaussian_filter(image, sigma, cval=0, mode="reflect")
+        image = ndi.gaussian_filter(image, sigma, cval=0, mode="mirror")
     zoom = [1 / f for f in factors]
-    return ndi.zoom(image, zoom, order=1, mode="reflect", cval=0, grid_mode=True).astype(out_dtype, copy=False)
+    return ndi.zoom(image, zoom, order=1, mode="mirror", cval=0, grid_mode=True).astype(out_dtype, copy=False)
 
 
 def resize_stack_on_device(stack_zxy, size: int, device, transpose_out: bool = True):
@@ -44,6 +63,8 @@ def resize_stack_on_device(stack_zxy, size: int, device, transpose_out: bool = T
     dev = torch.device(device)
     if dev.type != "cuda":
         raise cabi.DfxError("resize_stack_on_device runs on AMD GPUs only")
+    if isinstance(stack_zxy, np.ndarray) and stack_zxy.dtype.kind in "uib":
+        stack_zxy = as_float_like_skimage(stack_zxy)          # img_as_float's rescaling of integer stacks
     src = torch.as_tensor(stack_zxy)
     out_dtype = torch.float32 if src.dtype == torch.float32 else torch.float64
     src = src.to(dev, torch.float64).contiguous()

@@ -59,6 +59,8 @@ class HipKernels:
         self.v = self._v_own if self._v_own is not None else self.v_part.view(n_t, n_l, self.Xs, self.Ys)
         self.ra = self.rb = self.zab = None   # factored residual (new_factored_residual)
         self._last_slices = 1                 # launches the last sweep was cut into (post_sweep folds that many row sets)
+        self._reserved = []                   # 5-D vectors laid out together by reserve_vectors(), handed out in order
+        self.placement_info = None
         self.timing = None   # bench.py sets a dict: name -> list of (start, end) torch.cuda.Event pairs
         self.timing_names = None   # ... and, to time only some entry points (an event pair costs ~2 us of stream time), their names
 
@@ -83,8 +85,55 @@ class HipKernels:
     def slot_ptr(self, slot: int) -> int:
         return self.scal.data_ptr() + 8 * slot
 
+    def reserve_vectors(self, n: int, mode: str = "rank") -> None:
+        """Called once by a solver, before it takes its first 5-D vector, with the number of 5-D vectors it will sweep
+        in lock-step (x, p [, r]; x, exp_avg_sq [, exp_avg]).  mode "rank" and vectors of at least
+        placement.MIN_VECTOR_BYTES (8 GiB): all n are laid out together so that at equal offsets no two share a class
+        of device memory (datafusion_amd/placement.py; +16 % on the sweep of 16 GiB vectors) and new_vector() /
+        new_vector_paired() hand them out in order.  Otherwise, or when the pool cannot serve the request, nothing is
+        reserved and vectors come from torch (new_vector_paired then falls back to its probe)."""
+        from . import placement
+        self._reserved, self.placement_info = [], None
+        if mode != "rank" or n < 2 or 4 * self.N < placement.MIN_VECTOR_BYTES:
+            return
+        got = placement.pool(self.device).alloc_vectors(n, self.N)
+        if got is None:
+            return
+        vecs, self.placement_info = got
+        self._reserved = [v.view(self.shape) for v in vecs]
+        if self.plan.fast:
+            # check the layout with the real pass on the real vectors (a no-op sweep over zeroed operands, as in
+            # new_vector_paired): what the solver will get, recorded next to the layout
+            had = self.ra is not None
+            self.new_factored_residual()
+            saved = (self.ra.clone(), self.rb.clone(), self.scal.clone()) if had else (None, None, self.scal.clone())
+            self.ra.zero_(), self.rb.zero_()
+            self.scal[cabi.S_ALPHA], self.scal[cabi.S_BETA] = 0.0, 0.0
+            a, b = self._reserved[0].zero_(), self._reserved[1].zero_()
+            best = 1e30
+            for _ in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.device))
+                self.sweep(cabi.SWEEP_XP, a, None, b, factored=True)
+                e1.record(torch.cuda.current_stream(self.device))
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            self.placement_info["pair_sweep_GBps"] = 16.0 * self.N / best / 1e6
+            self.scal.copy_(saved[2])
+            if had:
+                self.ra.copy_(saved[0]), self.rb.copy_(saved[1])
+            else:
+                self.ra = self.rb = self.zab = None
+
     def new_vector(self) -> torch.Tensor:
-        return torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        if self._reserved:
+            return self._reserved.pop(0)
+        try:
+            return torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        except torch.cuda.OutOfMemoryError:
+            from . import placement
+            placement.trim(self.device)       # classified chunks kept for a later solve: the memory is needed now
+            return torch.empty(self.shape, dtype=torch.float32, device=self.device)
 
     def new_factored_residual(self) -> None:
         """Allocate the two factors of the CG residual, r = ra[z,x,y] + rb[t,l,x/r,y/r] (include/dfx.h), and the
@@ -127,8 +176,8 @@ class HipKernels:
           * vectors of 1 - 8 GiB (C2: 4 GiB) are far less sensitive (6.38 TB/s right behind `ref`, 6.47 TB/s some tens of
             GiB further on): three candidates, each pushed 32 GiB further by a spacer allocation."""
         nbytes = 4 * self.N
-        if tries <= 1 or nbytes < self.PAIR_PROBE_MIN_BYTES:
-            return self.new_vector()
+        if self._reserved or tries <= 1 or nbytes < self.PAIR_PROBE_MIN_BYTES:
+            return self.new_vector()           # reserved: already laid out against `ref` by reserve_vectors()
         big = nbytes >= self.PAIR_PROBE_BIG_BYTES
         if not big:
             tries = min(tries, 3)
@@ -245,31 +294,55 @@ class HipKernels:
 
     @_on_device
     def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step: int, non_neg: bool, m1a=None,
-                  m1b=None, fold: bool = True) -> None:
+                  m1b=None, fold: bool = True, slices: int = 1, after_slice=None) -> None:
         """One fused Adam iteration: x, m2 (and m1) in place; u(x_new) -> self.u, local v partial -> self.v;
         ADAM_DD = ||dx||^2, ADAM_XX = ||x_new||^2.  m1=None: the first moment is mask * (m1a + m1b), already advanced
-        by lerp() for this step (dfx_adam_step_factored)."""
+        by lerp() for this step (dfx_adam_step_factored).
+        slices > 1 / after_slice: as in sweep() - the pass is cut along the slab axis (dfx_adam_step_chunks) and
+        after_slice(v_rows) is called with each finished band of self.v, so that a z-sharded solve can start the
+        band's all-reduce while the rest of the volume is still being stepped."""
         self._chk(x, m1, m2, A, B, mask, m1a, m1b)
         assert x.numel() == m2.numel() == self.N and (m1 is None or m1.numel() == self.N)
         assert A.numel() == self.S and B.numel() == self.M * self.Xs * self.Ys and (mask is None or mask.numel() == self.S)
         g, pl = self._g()
         s = self._stream()
+        P = self.plan
         flags = (cabi.ADAM_NONNEG if non_neg else 0) | (0 if fold else cabi.ADAM_NOFOLD)
-        self._last_slices = 1
+        k = max(1, min(int(slices), P.cpb, cabi.MAX_SLICES)) if P.fast else 1
+        self._last_slices = k
         tail = (cabi.ptr(m2), cabi.ptr(A), cabi.ptr(B), cabi.ptr(mask), lr, beta1, beta2, eps, step, flags,
-                cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part), cabi.ptr(self.part), s)
-        if m1 is not None:
-            cabi.check(self._timed("adam", self.lib.dfx_adam_step, g, pl, cabi.ptr(x), cabi.ptr(m1), *tail),
-                       "dfx_adam_step")
-        else:
+                cabi.ptr(self.scal), cabi.ptr(self.u_part), cabi.ptr(self.v_part), cabi.ptr(self.part))
+        name = "adam" if m1 is not None else "adamf"
+        if m1 is None:
             assert m1a.numel() == self.S and m1b.numel() == self.M * self.Xs * self.Ys
-            cabi.check(self._timed("adamf", self.lib.dfx_adam_step_factored, g, pl, cabi.ptr(x), cabi.ptr(m1a),
-                                   cabi.ptr(m1b), *tail), "dfx_adam_step_factored")
+        if k == 1 and after_slice is None:
+            if m1 is not None:
+                cabi.check(self._timed(name, self.lib.dfx_adam_step, g, pl, cabi.ptr(x), cabi.ptr(m1), *tail, s),
+                           "dfx_adam_step")
+            else:
+                cabi.check(self._timed(name, self.lib.dfx_adam_step_factored, g, pl, cabi.ptr(x), cabi.ptr(m1a),
+                                       cabi.ptr(m1b), *tail, s), "dfx_adam_step_factored")
+        else:
+            gz = P.n_chunks // P.cpb
+            bounds = self._slice_bounds(P.cpb, k)
+            vrows = self.v.view(self.M, self.Xs * self.Ys)
+            for j in range(k):
+                c_lo, c_hi = bounds[j], bounds[j + 1]
+                cabi.check(self._timed(name, self.lib.dfx_adam_step_chunks, g, pl, cabi.ptr(x), cabi.ptr(m1),
+                                       cabi.ptr(m1a) if m1 is None else None, cabi.ptr(m1b) if m1 is None else None,
+                                       *tail, c_lo, c_hi, j, s), "dfx_adam_step_chunks")
+                m_lo, m_hi = min(c_lo * P.steps * gz, self.M), min(c_hi * P.steps * gz, self.M)
+                if m_hi <= m_lo or after_slice is None:
+                    continue
+                if self._v_own is not None:
+                    cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), m_lo, m_hi, s),
+                               "dfx_reduce_v")
+                after_slice(vrows[m_lo:m_hi])
         if not fold:
             return                                        # post_sweep(POST_U | POST_V | POST_FOLD_ADAM) follows
         cabi.check(self.lib.dfx_reduce_u(g, pl, cabi.ptr(self.u_part), cabi.ptr(self.u), cabi.ptr(self.scal),
                                          cabi.ptr(self.part), s), "dfx_reduce_u")
-        if self._v_own is not None:
+        if self._v_own is not None and after_slice is None:
             cabi.check(self.lib.dfx_reduce_v(g, pl, cabi.ptr(self.v_part), cabi.ptr(self.v), 0, self.M, s),
                        "dfx_reduce_v")
 

@@ -9,8 +9,9 @@
  * Conventions
  *   - every function returns 0 on success, a negative DFX_E* code for a rejected argument,
  *     or a positive hipError_t; dfx_last_error() gives the message (thread local).
- *   - no entry point allocates, frees or synchronises; the caller owns every buffer
- *     (sizes come from dfx_plan_make) and passes the hipStream_t to launch on.
+ *   - no entry point allocates, frees or synchronises (the dfx_arena_* set-up functions at the end of this
+ *     file excepted: they are the allocator); the caller owns every buffer (sizes come from dfx_plan_make)
+ *     and passes the hipStream_t to launch on.
  *   - pointers are device pointers; big vectors must be 16-byte aligned.
  *   - reductions are deterministic: per-workgroup double partials in the caller's `part`
  *     workspace, folded in a fixed order by a one-workgroup kernel launched by the same entry
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DFX_VERSION 120
+#define DFX_VERSION 130
 
 enum { DFX_EINVAL = -1, DFX_EALIGN = -2, DFX_EPLAN = -3 };
 
@@ -70,7 +71,8 @@ enum {
     DFX_S_SCALE = 16, /* dfx_recip output by convention                               */
     DFX_S_LOSS1 = 17, DFX_S_LOSS2 = 18, /* dfx_sqdiff outputs by convention           */
     DFX_S_ADAM_DD = 19, /* ||x_new - x_old||^2 of the last dfx_adam_step              */
-    DFX_S_ADAM_XX = 20, /* ||x_new||^2 of the last dfx_adam_step                      */
+    DFX_S_ADAM_XX = 20, /* ||x_new||^2 of the last dfx_adam_step; the Adam entry points also set
+                           TOL = sqrt(ADAM_DD / ADAM_XX) (fusion.py:244-252 as fusion.py:348 uses it) */
     DFX_S_RA2 = 21, DFX_S_RB2 = 22, DFX_S_RAB = 23, /* sum ra^2, sum rb^2, sum rb*zab of the last dfx_resid_update */
     DFX_S_ALPHA_LAST = 24, /* the alpha of the iteration dfx_cg_beta closed (ALPHA is renewed right after the sweep) */
     DFX_NSCAL = 32
@@ -206,6 +208,16 @@ int dfx_adam_step_factored(const dfx_geom *g, const dfx_plan *pl, float *x, cons
                            float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
                            double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
                            float *v_part, double *part, void *stream);
+/* The same two steps (optimizer.step() of fusion.py:340-346) cut along the slab axis like dfx_sweep_chunks, so that a
+ * z-sharded FusionAdam can all-reduce each finished band of v_part (the RD partials of the NEXT iteration's loss,
+ * fusion.py:226-232) while the rest of the volume is still being stepped: launch `slice` handles chunks [c_lo, c_hi)
+ * of the plan's cpb; slices in order; pass either m1 (explicit first moment) or m1a and m1b (factored), the other(s)
+ * NULL.  The slice with c_hi == cpb folds ADAM_DD, ADAM_XX over the rows of all slices unless DFX_ADAM_NOFOLD leaves
+ * them to dfx_post_sweep(DFX_POST_FOLD_ADAM, n_slices).  Fast plans only. */
+int dfx_adam_step_chunks(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1, const float *m1a, const float *m1b,
+                         float *m2, const float *A, const float *B, const float *mask, double lr, double beta1,
+                         double beta2, double eps, int32_t step, int32_t non_neg, double *scal, float *u_part,
+                         float *v_part, double *part, int32_t c_lo, int32_t c_hi, int32_t slice, void *stream);
 /* torch.optim.Adam's step (amsgrad=False, weight_decay=0) on an EXPLICIT gradient: the optimizer.step() of
  * fusion.py:342 when loss.backward() (fusion.py:338) has materialised x.grad - the autograd formulation, e.g. with
  * extra differentiable terms added to the loss.  x, grad, m1 (exp_avg), m2 (exp_avg_sq): n floats each, 16-byte
@@ -293,14 +305,40 @@ int dfx_baseline_init(const dfx_geom *g, const float *spc, const float *zw, floa
                       const double *coef_dev, double *scal, double *part, void *stream);
 
 /* Input stage, utils.py:411-427 (load_data): `skimage.transform.resize(cmos_xyz, (S1, S2, nZ))` with its defaults
- * (order 1, mode "reflect", anti-aliasing Gaussian sigma = (factor - 1) / 2 truncated at 4 sigma on the axes that
- * shrink), restated per plane of a float64 (planes, X, Y) stack on the device: out (planes, S1, S2), or
+ * (order 1, mode "reflect" - numpy.pad's name, which skimage hands to scipy.ndimage as "mirror": whole-sample
+ * symmetric, the edge sample not repeated -, anti-aliasing Gaussian sigma = (factor - 1) / 2 truncated at 4 sigma on the
+ * axes that shrink), restated per plane of a float64 (planes, X, Y) stack on the device: out (planes, S1, S2), or
  * (planes, S2, S1) when transpose_out (load_data's final np.transpose(., (2, 1, 0)) swaps x and y).
  * tmp_a, tmp_b: workspaces of planes*X*Y doubles each.  The z axis is not resized (factor 1).
  * scikit-image is not available to check against: PARITY UNPINNED; the tests compare with the scipy.ndimage calls
- * skimage's resize is built from (gaussian_filter + zoom(order=1, grid_mode=True)). */
+ * skimage's resize is built from (gaussian_filter + zoom(order=1, grid_mode=True), both with mode="mirror"). */
 int dfx_resize_stack(const double *in, double *tmp_a, double *tmp_b, double *out, int64_t planes, int64_t X,
                      int64_t Y, int64_t S1, int64_t S2, int32_t transpose_out, void *stream);
+
+/* ---- Placement of the 5-D vectors in device memory (set-up time; the ONLY entry points that allocate and
+ * synchronise).  No counterpart in the reference, whose vectors are whatever torch's allocator returns
+ * (fusion.py:196, 436, 445): on MI355X the 288 GiB fall into three classes of 96 GiB, and two vectors swept in
+ * lock-step stream at 6.4-6.5 TB/s when they lie in different classes at equal offsets, 5.4-5.5 TB/s when they share one
+ * (DESIGN.md "Placement of large vectors").  An arena owns physical chunks (hipMemCreate) of the CURRENT device; the
+ * caller measures each chunk's class (datafusion_amd/placement.py times the real sweep on pairs of chunks) and maps
+ * chunks, in an order of its choice, behind contiguous virtual ranges (hipMemAddressReserve + hipMemMap) that the
+ * other entry points then use like any device pointer.  A chunk is mapped in at most one view at a time. */
+typedef struct dfx_arena dfx_arena;
+/* n_chunks physical chunks of chunk_bytes each (rounded up to the device's recommended granularity). */
+int dfx_arena_create(int64_t chunk_bytes, int64_t n_chunks, dfx_arena **out);
+/* n_more further chunks (indices continue after the existing ones); all or nothing. */
+int dfx_arena_grow(dfx_arena *a, int64_t n_more);
+int dfx_arena_info(const dfx_arena *a, int64_t *chunk_bytes, int64_t *n_chunks, int32_t *device);
+/* A new view: chunks[0..n) mapped in that order at one contiguous, read-write virtual range -> *out_ptr. */
+int dfx_arena_map(dfx_arena *a, const int32_t *chunks, int64_t n, void **out_ptr);
+/* Remove the view whose base address is ptr (synchronises the device first); its chunks can be mapped again. */
+int dfx_arena_unmap(dfx_arena *a, void *ptr);
+/* Give unmapped chunks back to the driver (e.g. those the chosen layout does not use). */
+int dfx_arena_release_chunks(dfx_arena *a, const int32_t *chunks, int64_t n);
+/* Unmap every view, release every chunk, free the arena. */
+int dfx_arena_destroy(dfx_arena *a);
+/* Message of the last failed dfx_arena_* call on this thread. */
+const char *dfx_arena_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,9 @@ class CpuStandIn:
     def new_vector_paired(self, ref, tries=3):
         return self.new_vector()
 
+    def reserve_vectors(self, n, mode="rank"):
+        pass
+
     def new_vector(self):
         return torch.empty(self.shape)
 
@@ -138,7 +141,8 @@ class CpuStandIn:
     def lerp(self, m, g, weight):
         m.lerp_(g.reshape(m.shape), weight)
 
-    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, m1a=None, m1b=None, fold=True):
+    def adam_step(self, x, m1, m2, A, B, mask, lr, beta1, beta2, eps, step, non_neg, m1a=None, m1b=None, fold=True,
+                  slices=1, after_slice=None):
         n_z, X, Y = self.shape[2:]
 
         def expand(a, b):
@@ -163,6 +167,11 @@ class CpuStandIn:
         self._proj(x)
         self.scal[cabi.S_ADAM_DD] = ((x - x_old).double() ** 2).sum()
         self.scal[cabi.S_ADAM_XX] = (x.double() ** 2).sum()
+        if after_slice is not None:           # hand v over in `slices` bands, like the HIP backend
+            rows = self.v.view(self.M, -1)
+            k = max(1, min(slices, self.M))
+            for j in range(k):
+                after_slice(rows[self.M * j // k: self.M * (j + 1) // k])
 
     def sum_axis(self, x, axis):
         return x.sum(axis)

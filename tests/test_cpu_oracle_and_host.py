@@ -350,6 +350,18 @@ def test_load_data_input_stage(tmp_path):
     assert abs(out.mean() - ramp.mean()) < 5e-3 and np.all(np.diff(out[:, 0, 0]) > 0)
     # and feeds the solver's input contract: (t, l, x/r, y/r) and (z, x, y) with integer r
     assert c.shape[1] // s.shape[2] == 4 and c.shape[1] % s.shape[2] == 0
+    # the boundary rule is scipy's "mirror" - what skimage translates its default mode "reflect" to (_to_ndimage_mode):
+    # whole-sample symmetric, d c b | a b c d.  The first output of a 2x shrink by hand: sigma = 0.5, radius 2
+    sig = rng.uniform(0.0, 1.0, 8)
+    w = np.exp(-0.5 * np.arange(3) ** 2 / 0.25)
+    w /= w[0] + 2 * w[1:].sum()
+    f0 = w[0] * sig[0] + w[1] * (sig[1] + sig[1]) + w[2] * (sig[2] + sig[2])          # s[-1] = s[1], s[-2] = s[2]
+    f1 = w[0] * sig[1] + w[1] * (sig[0] + sig[2]) + w[2] * (sig[1] + sig[3])          # s[-1] = s[1]
+    got = resize_like_skimage(sig.reshape(8, 1, 1), (4, 1, 1))[:, 0, 0]
+    assert abs(got[0] - 0.5 * (f0 + f1)) < 1e-12
+    # integer stacks are rescaled like img_as_float (resize's preserve_range=False)
+    u16 = (rng.uniform(0, 1, (6, 6, 1)) * 65535).astype(np.uint16)
+    assert np.allclose(resize_like_skimage(u16, (6, 6, 1)), u16 / 65535.0, atol=1e-12)
 
 
 def test_integration_doc_struct_layout_matches_header():
@@ -428,3 +440,148 @@ def test_host_code_of_the_library_under_asan_and_ubsan(tmp_path):
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert p.returncode == 0 and "host_sanitize: OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+# ---------------------------------------------------------------- rank-aware placement (host logic, simulated memory)
+class _SimPool:
+    """DevicePool over a simulated GPU: chunk g lies in class phys[g]; the probe runs at 5500 GB/s when its two operands
+    share a class and 6450 when they do not (with a little noise), as measured on MI355X."""
+
+    def __new__(cls, phys, capacity, noise=0.0, seed=0):
+        import random
+        from datafusion_amd import placement
+
+        class Sim(placement.DevicePool):
+            def __init__(self):
+                self.device, self.index = "sim", 0
+                self.arena, self.n_chunks, self.cls, self.free = None, 0, {}, {}
+                self.same_rate, self.live_views, self.log, self._probe_k = None, 0, [], None
+                import threading
+                self.lock = threading.RLock()
+                self.rng = random.Random(seed)
+                self.mapped, self.owned, self.views, self.n_probes = {}, set(), {}, 0
+                self.slot = {}                                    # chunk id -> physical slot (the driver's choice)
+                self.free_slots = list(range(capacity))
+
+            def _create(self, n_more):
+                assert n_more <= len(self.free_slots)
+                ids = list(range(self.n_chunks, self.n_chunks + n_more))
+                self.n_chunks += n_more
+                self.owned |= set(ids)
+                for g in ids:
+                    self.slot[g] = self.free_slots.pop(0)         # lowest free physical slot first
+                self.arena = True
+                return ids
+
+            def _destroy_arena(self):
+                assert self.live_views == 0
+                self.free_slots = sorted(self.free_slots + [self.slot[g] for g in self.owned])
+                self.arena, self.n_chunks, self.cls, self.free, self.owned, self.slot = None, 0, {}, {}, set(), {}
+
+            def _map(self, ids):
+                assert all(g in self.owned and g not in self.mapped for g in ids)
+                base = (len(self.views) + 1 + self.rng.randrange(1000)) << 48
+                self.views[base] = list(ids)
+                for i, g in enumerate(ids):
+                    self.mapped[g] = base + i * placement.CHUNK_BYTES
+                return base
+
+            def _unmap(self, ptr):
+                for g in self.views.pop(ptr):
+                    del self.mapped[g]
+
+            def _release(self, ids):
+                for g in ids:
+                    assert g not in self.mapped
+                    self.owned.discard(g)
+                    self.cls.pop(g, None)
+                    self.free_slots.append(self.slot.pop(g))
+                self.free_slots.sort()
+
+            def _allocatable_chunks(self):
+                return len(self.free_slots)
+
+            def _chunk_at(self, ptr):
+                for g, a in self.mapped.items():
+                    if a <= ptr < a + placement.CHUNK_BYTES:
+                        return g
+                raise AssertionError("probe outside any mapped chunk")
+
+            def _rate(self, xptr, pptr, reps=2):
+                self.n_probes += 1
+                a, b = phys[self.slot[self._chunk_at(xptr)]], phys[self.slot[self._chunk_at(pptr)]]
+                return (5500.0 if a == b else 6450.0) * (1.0 + noise * (2 * self.rng.random() - 1))
+
+            def _zero(self, ptr, n_float):
+                self._chunk_at(ptr)
+
+            def _wrap(self, view, n_float):
+                return view          # the test keeps the view object itself alive
+
+            def _device_ctx(self):
+                import contextlib
+                return contextlib.nullcontext()
+
+            def trim_sim(self):
+                self.trim()
+
+        return Sim()
+
+
+@pytest.mark.parametrize("order", ["fresh", "scattered"])
+def test_rank_aware_pool_on_a_simulated_device(order):
+    """datafusion_amd/placement.py without a GPU: the classification (self-calibrated threshold, references tried most
+    recently matched first), the growth in batches, the layout, the reuse of classified chunks and the fallbacks."""
+    import random
+    from datafusion_amd import placement
+    n = 141
+    phys = [0] * 47 + [1] * 47 + [2] * 47            # what a fresh MI355X process is handed (r03_arena_probe.txt)
+    if order == "scattered":
+        random.Random(5).shuffle(phys)
+    chunk_f = placement.CHUNK_BYTES // 4
+    p = _SimPool(phys, n, noise=0.01)
+    # two 16 GiB vectors: 8 chunks each
+    vecs, info = p.alloc_vectors(2, 8 * chunk_f)
+    assert info["positions_sharing_a_class"] == 0 and info["chunks_per_vector"] == 8 and len(vecs) == 2
+    for a, b in zip(vecs[0].chunks, vecs[1].chunks):
+        assert phys[p.slot[a]] != phys[p.slot[b]]
+    assert len(p.owned) == 16 and p.live_views == 2 and not p.free          # spares went back to the driver
+    if order == "fresh":
+        assert info["chunks_created"] > 47                                  # had to allocate past the first class
+    created_first = info["chunks_created"]
+    # a request while those are alive cannot be served: the caller falls back to torch
+    assert p.alloc_vectors(2, 8 * chunk_f) is None
+    # freed vectors keep their classification: same request again, no probe
+    del vecs
+    probes = p.n_probes
+    vecs, info = p.alloc_vectors(2, 8 * chunk_f)
+    assert info["probes"] == 0 and p.n_probes == probes and info["positions_sharing_a_class"] == 0
+    del vecs
+    # three vectors (explicit residual): pairwise different at every position; the pool grows
+    vecs, info = p.alloc_vectors(3, 8 * chunk_f)
+    assert info["positions_sharing_a_class"] == 0
+    for t in zip(*(v.chunks for v in vecs)):
+        assert len({phys[p.slot[g]] for g in t}) == 3
+    del vecs
+    # the whole GPU: two vectors of 64 chunks each out of 141
+    vecs, info = p.alloc_vectors(2, 64 * chunk_f)
+    assert info["positions_sharing_a_class"] == 0
+    for a, b in zip(vecs[0].chunks, vecs[1].chunks):
+        assert phys[p.slot[a]] != phys[p.slot[b]]
+    assert len(p.owned) == 128
+    del vecs
+    # more than the device holds
+    assert p.alloc_vectors(2, 71 * chunk_f) is None
+    p.trim()
+    assert not p.owned and p.arena is None
+    assert created_first <= 141
+
+
+def test_rank_aware_layout_is_optimal_for_two_vectors_and_counts_conflicts():
+    from datafusion_amd.placement import DevicePool as P
+    assert P.conflicts(P.layout({0: 48, 1: 47, 2: 47}, 2, 64)) == 0
+    assert P.conflicts(P.layout({0: 47, 1: 47, 2: 47}, 3, 47)) == 0
+    assert P.conflicts(P.layout({0: 40, 1: 5}, 2, 20)) == 15             # only 5 positions can differ
+    assert P.layout({0: 3}, 2, 2) is None                               # not enough chunks at all
+    lay = P.layout({0: 10, 1: 10, 2: 10, 3: 1}, 2, 15)
+    assert P.conflicts(lay) == 0 and len(lay) == 15
