@@ -532,32 +532,38 @@ struct AdamArgs {
     int row0;         // first row of `part` this launch writes
 };
 
-template <bool M1F>
+// FAST: the hardware square root and reciprocal (1 ulp each; v_sqrt_f32 flushes denormal inputs, harmless while
+// eps > 0, which the fused entry points require) - the 5-D kernels of the fused FusionAdam path, where the IEEE
+// sequences made the pass VALU-bound.  !FAST: torch's arithmetic bit for bit (IEEE sqrt and division): k_adam_apply
+// (DfxAdam, which claims torch.optim.Adam's update and is bound by its seven memory streams either way) and the
+// generic kernel.
+template <bool M1F, bool FAST>
 __device__ __forceinline__ float adam_elem(float x, float g, float &m1, float &m2, const AdamArgs &a) {
     if (!M1F) m1 = m1 + a.omb1 * (g - m1);                // exp_avg.lerp_(grad, 1 - beta1); M1F: m1 is already new
     m2 = a.b2 * m2 + a.omb2 * (g * g);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-#if DFX_ADAM_FASTMATH
-    // the hardware square root and reciprocal are good to 1 ulp: the step changes by < 3e-7 of itself, far below one
-    // ulp of x for any step that does not swamp x; exp_avg_sq (the state carried on) is exact either way
-    const float denom = __builtin_amdgcn_sqrtf(m2) * a.inv_sqrt_bc2 + a.eps;
-    float xn = x - a.step_size * (m1 * __builtin_amdgcn_rcpf(denom));
-#else
-    const float denom = __fsqrt_rn(m2) * a.inv_sqrt_bc2 + a.eps;
-    float xn = x - a.step_size * __fdiv_rn(m1, denom);    // param.addcdiv_(exp_avg, denom, value=-step_size)
-#endif
+    float xn;
+    if (FAST) {
+        // the step changes by < 3e-7 of itself, far below one ulp of x for any step that does not swamp x; exp_avg_sq
+        // (the state carried on) is exact either way
+        const float denom = __builtin_amdgcn_sqrtf(m2) * a.inv_sqrt_bc2 + a.eps;
+        xn = x - a.step_size * (m1 * __builtin_amdgcn_rcpf(denom));
+    } else {
+        const float denom = __fsqrt_rn(m2) * a.inv_sqrt_bc2 + a.eps;
+        xn = x - a.step_size * __fdiv_rn(m1, denom);      // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
     if (a.non_neg) xn = fmaxf(xn, 0.f);                   // fusion.py:344-346
     return xn;
 }
 
-template <bool M1F>
+template <bool M1F, bool FAST = (DFX_ADAM_FASTMATH != 0)>
 __device__ __forceinline__ f4 adam_elem4(f4 x, f4 g, f4 &m1, f4 &m2, const AdamArgs &a) {
     float x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
     float p0 = m1.x, p1 = m1.y, p2 = m1.z, p3 = m1.w;
     float q0 = m2.x, q1 = m2.y, q2 = m2.z, q3 = m2.w;
-    x0 = adam_elem<M1F>(x0, g.x, p0, q0, a);
-    x1 = adam_elem<M1F>(x1, g.y, p1, q1, a);
-    x2 = adam_elem<M1F>(x2, g.z, p2, q2, a);
-    x3 = adam_elem<M1F>(x3, g.w, p3, q3, a);
+    x0 = adam_elem<M1F, FAST>(x0, g.x, p0, q0, a);
+    x1 = adam_elem<M1F, FAST>(x1, g.y, p1, q1, a);
+    x2 = adam_elem<M1F, FAST>(x2, g.z, p2, q2, a);
+    x3 = adam_elem<M1F, FAST>(x3, g.w, p3, q3, a);
     m1 = (f4){p0, p1, p2, p3};
     m2 = (f4){q0, q1, q2, q3};
     return (f4){x0, x1, x2, x3};
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(256) void k_adam_apply(float *x, const float *g, fl
         for (int u = 0; u < UNROLL; ++u) {
             const long long i = i0 + u * stride;
             if (i < n4) {
-                const f4 xn = adam_elem4<false>(xv[u], gv[u], e1[u], e2[u], a);
+                const f4 xn = adam_elem4<false, false>(xv[u], gv[u], e1[u], e2[u], a);
                 st4s(x + 4 * i, xn);
                 st4s(m1 + 4 * i, e1[u]);
                 st4s(m2 + 4 * i, e2[u]);
@@ -724,7 +730,7 @@ __global__ __launch_bounds__(256) void k_adam_apply(float *x, const float *g, fl
     }
     for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {   // tail (n % 4)
         float e1 = m1[i], e2 = m2[i];
-        const float xo = x[i], xn = adam_elem<false>(xo, g[i], e1, e2, a);
+        const float xo = x[i], xn = adam_elem<false, false>(xo, g[i], e1, e2, a);
         x[i] = xn, m1[i] = e1, m2[i] = e2;
         ddd += (double)((xn - xo) * (xn - xo));
         dxx += (double)(xn * xn);
@@ -747,12 +753,12 @@ __global__ __launch_bounds__(256) void k_gen_adam(AdamArgs a) {
         float e1, e2 = a.m2[i], xn;
         if (a.m1) {
             e1 = a.m1[i];
-            xn = adam_elem<false>(xo, g, e1, e2, a);
+            xn = adam_elem<false, false>(xo, g, e1, e2, a);
             a.m1[i] = e1;
         } else {
             e1 = a.m1a[j] + a.m1b[jb];
             if (a.mask) e1 *= a.mask[j];
-            xn = adam_elem<true>(xo, g, e1, e2, a);
+            xn = adam_elem<true, false>(xo, g, e1, e2, a);
         }
         a.x[i] = xn;
         a.m2[i] = e2;
@@ -1876,6 +1882,8 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
         return fail(DFX_EINVAL, "dfx_adam_step: NULL buffer");
     if (step < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1))
         return fail(DFX_EINVAL, "dfx_adam_step: step >= 1 and betas in [0, 1) required");
+    if (!(eps > 0))   // the fast kernels' hardware sqrt flushes denormal exp_avg_sq: only eps keeps the quotient finite
+        return fail(DFX_EINVAL, "dfx_adam_step: eps > 0 required");
     hipStream_t st = (hipStream_t)stream;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     AdamArgs a{x, m1, m2, m1a, m1b, A, B, mask, u_part, v_part, part, (float)beta1, (float)beta2,

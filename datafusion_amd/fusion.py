@@ -63,6 +63,9 @@ class SumPoolOperator:
     def __init__(self, size: int = 4, channels: int = 16, device: str = "cuda"):
         self.size = size
         self.channels = channels
+        # fusion.py:75: the depthwise ones kernel of the reference's conv2d / conv_transpose2d.  Kept as an attribute
+        # for callers that read it; dfx_block_sum / dfx_block_expand need no kernel tensor
+        self.kernel = torch.ones((channels, 1, size, size), dtype=torch.float32, device=device)
 
     def T(self, y: torch.Tensor) -> torch.Tensor:
         return kernels.op_block_expand(y, int(self.size))                        # fusion.py:84-87

@@ -6,8 +6,15 @@ torch's default (foreach) Adam makes seven full passes over x, grad, exp_avg, ex
 52 launches on a 4 GiB parameter; dfx_adam_apply reads the four arrays and writes three in one pass, fuses the optional
 non-negativity clamp (fusion.py:344-346) and returns ||x_new - x_old||^2 and ||x_new||^2, so the tolerance of
 fusion.py:244-252 needs neither the clone of fusion.py:329 nor a subtraction pass.
-State keys are torch.optim.Adam's ("step", "exp_avg", "exp_avg_sq").  No CPU path: parameters must be float32,
-contiguous, on an AMD GPU.
+State: exactly torch.optim.Adam's keys ("step", "exp_avg", "exp_avg_sq"), so state_dict() / load_state_dict()
+round-trip with a torch.optim.Adam of the same parameters ("step" is kept as torch keeps it: a 0-dim float32 tensor;
+a plain number is accepted).  The launch's scratch (scalars + per-workgroup partials, 576 KiB per device) lives
+outside the state.  The update uses the IEEE square root and division like torch's (the 5-D kernels of the fused
+FusionAdam path use the 1-ulp hardware approximations; this one is bound by its seven memory streams either way); the
+bias correction of the denominator is a multiplication by 1 / sqrt(1 - beta2^t) where torch divides, so the last bit
+can differ from torch.optim.Adam's.
+`last_sq_norms` holds ||x_new - x_old||^2 and ||x_new||^2 SUMMED over every parameter stepped by the last step().
+No CPU path: parameters must be float32, contiguous, on an AMD GPU.
 """
 from __future__ import annotations
 
@@ -21,9 +28,15 @@ class DfxAdam(torch.optim.Optimizer):
                  n_blocks: int = 0):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("DfxAdam: lr, eps >= 0 and betas in [0, 1) required")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, non_neg=non_neg))
+        # the param-group keys of torch.optim.Adam as well (fixed to what this optimizer implements), so that a
+        # state_dict() of either optimizer loads into the other
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, non_neg=non_neg, weight_decay=0, amsgrad=False,
+                                      maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
+        self._non_neg = bool(non_neg)
         self.n_blocks = int(n_blocks)
-        self.last_sq_norms = None   # device tensor (2,) float64: ||dx||^2, ||x||^2 of the last parameter stepped
+        self.last_sq_norms = None   # device tensor (2,) float64: ||dx||^2, ||x||^2 over the parameters of the last step()
+        self._scratch = {}          # device -> (scal, part): launch scratch, not optimizer state
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -32,7 +45,11 @@ class DfxAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = cabi.lib()
+        total = None
         for group in self.param_groups:
+            if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
+                raise cabi.DfxError("DfxAdam implements Adam with weight_decay=0, amsgrad=False, maximize=False only")
+            non_neg = group.get("non_neg", self._non_neg)      # absent after loading a torch.optim.Adam checkpoint
             for p in group["params"]:
                 g = p.grad
                 if g is None:
@@ -43,19 +60,29 @@ class DfxAdam(torch.optim.Optimizer):
                     raise cabi.DfxError("DfxAdam does not take sparse gradients")
                 g = g.contiguous()
                 st = self.state[p]
-                if not st:
-                    st["step"] = 0
+                if "exp_avg" not in st:                       # fresh, or a state that holds only a step count
+                    st.setdefault("step", torch.zeros((), dtype=torch.float32))
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["_scal"] = torch.zeros(cabi.NSCAL, dtype=torch.float64, device=p.device)
-                    st["_part"] = torch.empty(cabi.EW_MAXBLOCKS * cabi.NPART, dtype=torch.float64, device=p.device)
-                st["step"] += 1
+                for key in ("exp_avg", "exp_avg_sq"):         # e.g. loaded from a checkpoint taken on another device
+                    if st[key].device != p.device or st[key].dtype != torch.float32 or not st[key].is_contiguous():
+                        st[key] = st[key].to(device=p.device, dtype=torch.float32).contiguous()
+                step = int(st["step"]) + 1                    # tensor (torch.optim.Adam's) or number
+                st["step"] = st["step"] + 1 if isinstance(st["step"], torch.Tensor) else step
+                if p.device not in self._scratch:
+                    self._scratch[p.device] = (torch.zeros(cabi.NSCAL, dtype=torch.float64, device=p.device),
+                                               torch.empty(cabi.EW_MAXBLOCKS * cabi.NPART, dtype=torch.float64,
+                                                           device=p.device))
+                scal, part = self._scratch[p.device]
                 with torch.cuda.device(p.device):
                     cabi.check(lib.dfx_adam_apply(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
                                                   st["exp_avg_sq"].data_ptr(), p.numel(), group["lr"], group["betas"][0],
-                                                  group["betas"][1], group["eps"], st["step"],
-                                                  cabi.ADAM_NONNEG if group["non_neg"] else 0, self.n_blocks,
-                                                  st["_scal"].data_ptr(), st["_part"].data_ptr(),
+                                                  group["betas"][1], group["eps"], step,
+                                                  cabi.ADAM_NONNEG if non_neg else 0, self.n_blocks,
+                                                  scal.data_ptr(), part.data_ptr(),
                                                   torch.cuda.current_stream(p.device).cuda_stream), "dfx_adam_apply")
-                self.last_sq_norms = st["_scal"][cabi.S_ADAM_DD:cabi.S_ADAM_XX + 1]
+                norms = scal[cabi.S_ADAM_DD:cabi.S_ADAM_XX + 1]
+                total = norms.clone() if total is None else total + norms.to(total.device)
+        if total is not None:
+            self.last_sq_norms = total
         return loss

@@ -36,6 +36,7 @@ MIN_VECTOR_BYTES = int(os.environ.get("DFX_ARENA_MIN_VECTOR_MIB", 8192)) << 20
 # one chunk 5.3 - 5.7 TB/s, two chunks of one class 5.45 - 5.9, chunks of different classes 6.1 - 6.45
 SAME_CLASS = 1.08
 CALIBRATION_CHUNKS = 5
+MAX_CHUNKS = 192            # an arena never holds more (288 GiB / 2 GiB = 144 on an MI355X)
 
 
 class _View:
@@ -74,6 +75,7 @@ class DevicePool:
         self.free = {}                   # class id -> [chunk ids]
         self.same_rate = None            # GB/s of the probe on two halves of one chunk (a pair sharing a class)
         self.live_views = 0
+        self.exhausted = False           # the last growth took all it may and a layout still had conflicts
         self.lock = threading.RLock()
         self.log = []                    # what happened, for bench / tests
         self._probe_k = None
@@ -103,7 +105,7 @@ class DevicePool:
             assert self.live_views == 0
             with torch.cuda.device(self.index):
                 cabi.check(cabi.lib().dfx_arena_destroy(self.arena), "dfx_arena_destroy")
-        self.arena, self.n_chunks, self.cls, self.free = None, 0, {}, {}
+        self.arena, self.n_chunks, self.cls, self.free, self.exhausted = None, 0, {}, {}, False
 
     def _map(self, ids):
         arr = (C.c_int32 * len(ids))(*ids)
@@ -125,7 +127,8 @@ class DevicePool:
 
     def _allocatable_chunks(self) -> int:
         torch.cuda.empty_cache()
-        return int(max(0, (torch.cuda.mem_get_info(self.index)[0] - RESERVE_BYTES) // CHUNK_BYTES))
+        room = int(max(0, (torch.cuda.mem_get_info(self.index)[0] - RESERVE_BYTES) // CHUNK_BYTES))
+        return max(0, min(room, MAX_CHUNKS - len(self.cls)))
 
     def _device_ctx(self):
         return torch.cuda.device(self.index)
@@ -180,6 +183,13 @@ class DevicePool:
             best = min(best, e0.elapsed_time(e1))
         return 16.0 * k.N / best / 1e6
 
+    def _pair_rate(self, a, b, at, off, reps=2):
+        """The probe on chunks a and b mapped at at[a], at[b]: x in a at byte offset `off` (0 or half a chunk), p in b
+        at `off` - or, for a == b, x in the first half and p in the second (a pair that shares a class for sure)."""
+        if a == b:
+            return self._rate(at[a], at[a] + off, reps)
+        return self._rate(at[a] + off, at[b] + off, reps)
+
     def _zero(self, ptr, n_float):
         torch.as_tensor(_Raw(ptr, n_float), device=self.device).zero_()
 
@@ -200,7 +210,7 @@ class DevicePool:
             for g in new_ids:                             # fresh physical memory: make what the probe reads finite
                 self._zero(at[g], CHUNK_BYTES // 4)
             if self.same_rate is None:
-                own = sorted(self._rate(at[g], at[g] + half, reps=3) for g in new_ids[:CALIBRATION_CHUNKS])
+                own = sorted(self._pair_rate(g, g, at, half, reps=3) for g in new_ids[:CALIBRATION_CHUNKS])
                 self.same_rate = own[len(own) // 2]
                 probes += len(own)
             thr = SAME_CLASS * self.same_rate
@@ -208,10 +218,10 @@ class DevicePool:
             for g in new_ids:
                 found = None
                 for c in order:
-                    r = self._rate(at[refs[c]], at[g])
+                    r = self._pair_rate(refs[c], g, at, 0)
                     probes += 1
                     if thr * 0.97 < r < thr * 1.04:       # too close to call: the best of more runs, on the chunks' other
-                        r = max(r, self._rate(at[refs[c]] + half, at[g] + half, reps=4))   # halves (noise only lowers a rate)
+                        r = max(r, self._pair_rate(refs[c], g, at, half, reps=4))   # halves (noise only lowers a rate)
                         probes += 1
                     rates.append(r)
                     if r < thr:
@@ -274,7 +284,7 @@ class DevicePool:
 
             counts, lay = plan()
             probes = created = 0
-            if lay is None or self.conflicts(lay):
+            if lay is None or (self.conflicts(lay) and not self.exhausted):
                 if self.live_views:
                     return None
                 if sum(counts.values()) + self._allocatable_chunks() < need:
@@ -296,6 +306,9 @@ class DevicePool:
                 if lay is None:
                     self.trim()
                     return None
+                # everything that may be taken has been looked at and two vectors still meet in one class somewhere:
+                # later requests that the free chunks can serve take them as they are (until trim())
+                self.exhausted = bool(self.conflicts(lay))
             vec_chunks = [[] for _ in range(n_vectors)]
             for pos in lay:
                 for j, c in enumerate(pos):
@@ -328,6 +341,20 @@ def pool(device) -> DevicePool:
         if idx not in _pools:
             _pools[idx] = DevicePool(torch.device("cuda", idx))
         return _pools[idx]
+
+
+def available_bytes(device) -> int:
+    """Device memory a solve could still get: what the driver reports free plus the classified chunks this process's
+    pool holds on its free lists."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    free = torch.cuda.mem_get_info(idx)[0]
+    with _pools_lock:
+        p = _pools.get(idx)
+    if p is not None:
+        with p.lock:
+            free += CHUNK_BYTES * sum(len(v) for v in p.free.values())
+    return int(free)
 
 
 def trim(device=None) -> None:

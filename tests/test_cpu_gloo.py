@@ -37,8 +37,17 @@ def _worker(rank, world, port, case, q):
         else:
             assert f.comm_probe is None and f.comm_slices == case["slices"]
     else:
-        f = FusionAdam(spc, cmos, fused=case.get("fused", True), moment1=case.get("moment1", "factored"), **kw)
+        f = FusionAdam(spc, cmos, fused=case.get("fused", True), moment1=case.get("moment1", "factored"),
+                       comm_slices=case.get("slices", "auto"), **kw)
         x, _, _ = f(lr=1e-7, max_iterations=case["iters"], return_numpy=False)
+        if case.get("fused", True):
+            assert f.comm_slices == (case["slices"] if "slices" in case else f.comm_probe["slices"])
+        # the public tolerance() after an Adam call is ||x - prev_x|| / ||x|| of the last step over ALL shards (a
+        # collective): every rank gets the same number
+        tol = float(f.tolerance())
+        tols = [None] * world
+        dist.all_gather_object(tols, tol)
+        assert tol > 0 and len(set(tols)) == 1
     l1, l2 = f.loss()
     parts = [None] * world
     dist.all_gather_object(parts, (f.z_range, x.detach().numpy()))
@@ -109,6 +118,15 @@ def test_gloo_adam_fused_explicit_first_moment():
 
 def test_gloo_adam_autograd():
     _check(dict(method="adam", init="baseline", tol=1e-12, mask=False, defer=True, iters=4, fused=False), 29614)
+
+
+def test_gloo_adam_fixed_slicing_three_bands_and_one_band():
+    """Sharded FusionAdam hands v over in bands like FusionCG (the all-reduce of each band overlaps the rest of the
+    step): 3 bands and 1 band give the same iterate, bit for bit, and the oracle's."""
+    a = _run(dict(method="adam", init="baseline", tol=None, mask=True, defer=True, iters=4, slices=3), 29620)
+    b = _run(dict(method="adam", init="baseline", tol=None, mask=True, defer=True, iters=4, slices=1), 29621)
+    assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    _check(dict(method="adam", init="baseline", tol=None, mask=False, defer=True, iters=4, slices=3, moment1="explicit"), 29622)
 
 
 def test_gloo_cg_fixed_slicing_three_bands_and_one_band():

@@ -69,8 +69,9 @@ _collapsed_cache = {}
 
 
 def _need_free(n_bytes, what):
+    from datafusion_amd import placement
     torch.cuda.empty_cache()
-    free = torch.cuda.mem_get_info()[0]
+    free = placement.available_bytes(DEV)      # what the driver has + the classified chunks the process's pool keeps
     if free < n_bytes:
         msg = f"{what}: needs {n_bytes / GIB:.0f} GiB of free device memory, {free / GIB:.0f} GiB available"
         print("SKIP", msg)
@@ -274,6 +275,18 @@ def _rccl_worker(port, q):
     probe = f.comm_probe                     # comm_slices="auto": one timed all-reduce of v decided the slicing
     del f, g
     torch.cuda.empty_cache()
+    # sharded FusionAdam hands v over in bands (dfx_adam_step_chunks): a geometry with 4 chunks per workgroup, 3 bands
+    # vs 1 band vs no group at all
+    spc, cmos = Or.synthetic_inputs(32, 32, 4, 256, 4, seed=8)
+    adam = []
+    for kw in (dict(group=dist.group.WORLD, comm_slices=3), dict(group=dist.group.WORLD, comm_slices=1), dict()):
+        for m1 in ("factored", "explicit"):
+            a = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, moment1=m1, **kw)
+            xs, _, _ = a(lr=1e-9, max_iterations=3, return_numpy=False)
+            adam.append((m1, kw.get("comm_slices", 0), a.k.plan.cpb, a.k._last_slices, _bit_checksum(xs.detach()),
+                         float(a.tolerance())))
+            del a, xs
+    torch.cuda.empty_cache()
     # config 3's per-GPU slab at G = 8: its 256 MiB v all-reduced in 6 bands while the sweep goes on
     big = None
     if torch.cuda.mem_get_info()[0] > 40 * (1 << 30):
@@ -282,7 +295,7 @@ def _rccl_worker(port, q):
                      comm_slices=6)
         xb, _, _ = h(5, return_numpy=False)
         big = (_bit_checksum(xb), h.k.v.numel() * 4, h.comm_slices)
-    q.put((x, it, xa, probe, big))
+    q.put((x, it, xa, probe, big, adam))
     dist.destroy_process_group()
 
 
@@ -292,9 +305,13 @@ def test_collectives_through_real_rccl_one_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(29641, q))
     p.start()
-    x, it, xa, probe, big = q.get(timeout=200)
+    x, it, xa, probe, big, adam = q.get(timeout=200)
     p.join(60)
     assert p.exitcode == 0
+    for m1 in ("factored", "explicit"):
+        rows = [r for r in adam if r[0] == m1]
+        assert [r[1] for r in rows] == [3, 1, 0] and rows[0][2] >= 3 and [r[3] for r in rows] == [3, 1, 1], rows
+        assert rows[0][4] == rows[1][4] == rows[2][4] and rows[0][5] == rows[1][5] == rows[2][5] > 0, rows
     assert probe is not None and 1 <= probe["slices"] <= 16 and probe["allreduce_v_s"] > 0, probe
     print("one-rank RCCL all-reduce probe:", probe)
     if big is not None:
@@ -391,6 +408,9 @@ def test_bench_prints_one_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
     assert d["config"]["residual"] == "factored" and d["other_residual_mode"]["residual"] == "explicit"
+    # the CPU leg's iterate is compared with the HIP path's on the same inputs; above 1e-4 bench.py exits non-zero
+    assert d["parity"]["ok"] and d["parity"]["rel_l2_vs_cpu_oracle"] <= 1e-4 and d["parity"]["iterations"] == 2
+    assert d["timed_blocks"]["repeats"] == 3 and len(d["timed_blocks"]["ms_per_step"]) == 3
 
 
 def test_c_abi_without_python_or_torch():
