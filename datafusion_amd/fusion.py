@@ -63,9 +63,16 @@ class SumPoolOperator:
     def __init__(self, size: int = 4, channels: int = 16, device: str = "cuda"):
         self.size = size
         self.channels = channels
-        # fusion.py:75: the depthwise ones kernel of the reference's conv2d / conv_transpose2d.  Kept as an attribute
-        # for callers that read it; dfx_block_sum / dfx_block_expand need no kernel tensor
-        self.kernel = torch.ones((channels, 1, size, size), dtype=torch.float32, device=device)
+        self._device = device
+        self._kernel = None
+
+    @property
+    def kernel(self) -> torch.Tensor:
+        """fusion.py:75: the depthwise ones kernel of the reference's conv2d / conv_transpose2d, for callers that read
+        it (built on first use; dfx_block_sum / dfx_block_expand need no kernel tensor)."""
+        if self._kernel is None:
+            self._kernel = torch.ones((self.channels, 1, self.size, self.size), dtype=torch.float32, device=self._device)
+        return self._kernel
 
     def T(self, y: torch.Tensor) -> torch.Tensor:
         return kernels.op_block_expand(y, int(self.size))                        # fusion.py:84-87
