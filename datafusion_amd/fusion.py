@@ -148,7 +148,7 @@ class Fusion:
             raise ValueError("placement must be 'rank', 'probe' or 'plain'")
         if placement == "plain":
             self.placement_tries = 1
-        self.k.reserve_vectors(self._n_volumes(), placement)
+        self.k.reserve_vectors(self._n_volumes(), placement, self._placement_min_bytes())
         self._cmos_loc = self.cmos[z0:z1].contiguous()
         self._cmask_loc = self.cmos_mask[z0:z1].float().contiguous()
         self._smask_f = self.spc_mask.float().contiguous()
@@ -182,6 +182,10 @@ class Fusion:
     def _n_volumes(self) -> int:
         """5-D vectors this solver sweeps in lock-step (x included); 0: not known here."""
         return 0
+
+    def _placement_min_bytes(self):
+        """Vector size from which the vectors are laid out by memory class; None: placement.MIN_VECTOR_BYTES."""
+        return None
 
     def _initialize(self) -> torch.Tensor:
         """fusion.py:254-272 + the masking / normalisation of fusion.py:197-199, on the device."""
@@ -573,6 +577,7 @@ class FusionAdam(Fusion):
         self._m1 = self._m2 = self._m1a = self._m1b = self._gA = self._gB = None
         self._adam_step = 0
         self._last_norms = None
+        self._auto_bufs = None
 
     def tolerance(self) -> torch.Tensor:
         """fusion.py:244-252 as FusionAdam uses it (fusion.py:348): ||x - prev_x|| / ||x|| of the last step; prev_x is
@@ -585,8 +590,15 @@ class FusionAdam(Fusion):
         return torch.sqrt(d[0] / d[1]).float()
 
     def _n_volumes(self) -> int:
-        # fused: x, exp_avg_sq (, exp_avg); the autograd formulation allocates its gradient per backward(): not planned
-        return (2 if self.moment1 == "factored" else 3) if self.fused else 0
+        # fused: x, exp_avg_sq (, exp_avg); the autograd formulation: x, exp_avg, exp_avg_sq (its gradient is a fresh
+        # allocation of every backward(), wherever torch puts it)
+        return (2 if self.moment1 == "factored" else 3) if self.fused else 3
+
+    def _placement_min_bytes(self):
+        # the optimizer step of the autograd formulation (dfx_adam_apply: seven streams over four arrays) gains from
+        # spreading its arrays over the memory classes already at C2's 4 GiB (0.72 -> 0.78 of peak, 145 -> 157 it/s);
+        # the two-vector sweeps only from 8 GiB on (measured: tools/exp_c2_min_vector.sh)
+        return None if self.fused else (1 << 30)
 
     def loss_autograd(self, mask_grad: bool = False):
         return _FusionLossFn.apply(self.x, self, mask_grad)
@@ -664,7 +676,10 @@ class FusionAdam(Fusion):
         """fusion.py:324-358 as written there - loss() through autograd, an optimizer step on the explicit gradient -
         with the loss as one autograd node over the HIP kernels and torch.optim.Adam's update as one launch (DfxAdam:
         the clamp of fusion.py:344-346 and the norms of the tolerance are fused into it)."""
-        optimizer = self.k.adam_optimizer([self.x], lr, self.betas, self.adam_eps, non_neg)     # DfxAdam
+        if self._auto_bufs is None and self.k.reserved_left() >= 2:
+            self._auto_bufs = (self.k.new_vector(), self.k.new_vector())       # laid out next to x by memory class
+        bufs = {self.x: self._auto_bufs} if self._auto_bufs is not None else None
+        optimizer = self.k.adam_optimizer([self.x], lr, self.betas, self.adam_eps, non_neg, bufs)     # DfxAdam
         for i in range(max_iterations):
             self.curr_iter += 1
             optimizer.zero_grad()

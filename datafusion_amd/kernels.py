@@ -85,7 +85,7 @@ class HipKernels:
     def slot_ptr(self, slot: int) -> int:
         return self.scal.data_ptr() + 8 * slot
 
-    def reserve_vectors(self, n: int, mode: str = "rank") -> None:
+    def reserve_vectors(self, n: int, mode: str = "rank", min_bytes: int | None = None) -> None:
         """Called once by a solver, before it takes its first 5-D vector, with the number of 5-D vectors it will sweep
         in lock-step (x, p [, r]; x, exp_avg_sq [, exp_avg]).  mode "rank" and vectors of at least
         placement.MIN_VECTOR_BYTES (8 GiB): all n are laid out together so that at equal offsets no two share a class
@@ -94,7 +94,7 @@ class HipKernels:
         reserved and vectors come from torch (new_vector_paired then falls back to its probe)."""
         from . import placement
         self._reserved, self.placement_info = [], None
-        if mode != "rank" or n < 2 or 4 * self.N < placement.MIN_VECTOR_BYTES:
+        if mode != "rank" or n < 2 or 4 * self.N < (placement.MIN_VECTOR_BYTES if min_bytes is None else min_bytes):
             return
         got = placement.pool(self.device).alloc_vectors(n, self.N)
         if got is None:
@@ -359,11 +359,15 @@ class HipKernels:
                                0 if smask is None else smask.numel(), cabi.ptr(B), cabi.ptr(m1b), B.numel(), w1, w2,
                                lerp_weight, cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_adam_prep")
 
+    def reserved_left(self) -> int:
+        return len(self._reserved)
+
     @staticmethod
-    def adam_optimizer(params, lr, betas, eps, non_neg):
-        """The optimizer of the autograd formulation (fusion.py:325): torch.optim.Adam's update as one launch."""
+    def adam_optimizer(params, lr, betas, eps, non_neg, moment_buffers=None):
+        """The optimizer of the autograd formulation (fusion.py:325): torch.optim.Adam's update as one launch;
+        moment_buffers: {parameter: (exp_avg, exp_avg_sq)} placed by the caller (reserve_vectors) or None."""
         from .optim import DfxAdam
-        return DfxAdam(params, lr=lr, betas=betas, eps=eps, non_neg=non_neg)
+        return DfxAdam(params, lr=lr, betas=betas, eps=eps, non_neg=non_neg, moment_buffers=moment_buffers)
 
     @_on_device
     def lerp(self, m, g, weight: float) -> None:

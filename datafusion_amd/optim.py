@@ -25,7 +25,11 @@ from . import _cabi as cabi
 
 class DfxAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, non_neg: bool = False,
-                 n_blocks: int = 0):
+                 n_blocks: int = 0, moment_buffers=None):
+        """moment_buffers: optional {parameter: (exp_avg, exp_avg_sq)} of caller-placed tensors shaped like the
+        parameter (FusionAdam passes vectors laid out by memory class next to x, datafusion_amd/placement.py: the
+        step's seven streams run at 0.78 of the HBM peak spread over two or more classes, 0.72 inside one); they are
+        zeroed when first used.  Default: torch.zeros_like."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("DfxAdam: lr, eps >= 0 and betas in [0, 1) required")
         # the param-group keys of torch.optim.Adam as well (fixed to what this optimizer implements), so that a
@@ -34,6 +38,7 @@ class DfxAdam(torch.optim.Optimizer):
                                       maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                                       decoupled_weight_decay=False))
         self._non_neg = bool(non_neg)
+        self._moment_buffers = dict(moment_buffers or {})
         self.n_blocks = int(n_blocks)
         self.last_sq_norms = None   # device tensor (2,) float64: ||dx||^2, ||x||^2 over the parameters of the last step()
         self._scratch = {}          # device -> (scal, part): launch scratch, not optimizer state
@@ -62,8 +67,12 @@ class DfxAdam(torch.optim.Optimizer):
                 st = self.state[p]
                 if "exp_avg" not in st:                       # fresh, or a state that holds only a step count
                     st.setdefault("step", torch.zeros((), dtype=torch.float32))
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    bufs = self._moment_buffers.pop(p, None)
+                    if bufs is not None:
+                        st["exp_avg"], st["exp_avg_sq"] = bufs[0].view(p.shape).zero_(), bufs[1].view(p.shape).zero_()
+                    else:
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 for key in ("exp_avg", "exp_avg_sq"):         # e.g. loaded from a checkpoint taken on another device
                     if st[key].device != p.device or st[key].dtype != torch.float32 or not st[key].is_contiguous():
                         st[key] = st[key].to(device=p.device, dtype=torch.float32).contiguous()

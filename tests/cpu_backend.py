@@ -31,8 +31,11 @@ class _CpuAdam(torch.optim.Adam):
 
 class CpuStandIn:
     @staticmethod
-    def adam_optimizer(params, lr, betas, eps, non_neg):
+    def adam_optimizer(params, lr, betas, eps, non_neg, moment_buffers=None):
         return _CpuAdam(params, lr, betas, eps, non_neg)
+
+    def reserved_left(self):
+        return 0
 
     def __init__(self, n_t, n_l, n_z_local, X, Y, r, device, target_blocks=0):
         self.device = torch.device("cpu")
@@ -73,7 +76,7 @@ class CpuStandIn:
     def new_vector_paired(self, ref, tries=3):
         return self.new_vector()
 
-    def reserve_vectors(self, n, mode="rank"):
+    def reserve_vectors(self, n, mode="rank", min_bytes=None):
         pass
 
     def new_vector(self):
