@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
-PMC_RECORD = "r02_pmc_traffic.json"   # written by tools/profile_all.sh; carries the sha256 of the kernel source it was taken on
+PMC_RECORD = "r03_pmc_traffic.json"   # written by tools/profile_all.sh; carries the sha256 of the kernel source it was taken on
 
 WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "c2": (256, 16, 16, 128, 4),

@@ -154,7 +154,9 @@ int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, floa
  * (zab + the per-workgroup partials, 576 KiB) is a static __device__ array inside the library, one copy per GPU,
  * held until the process ends.  Limits: (X/r)*(Y/r) <= DFX_NOALLOC_MAX_PS, else DFX_EINVAL; the device of `stream`
  * must be the current device; every call on one GPU shares that GPU's scratch, so calls that overlap on one GPU
- * (two streams) race - serialise them.  Calls no hipMalloc / hipFree, and does not synchronise. */
+ * (two streams) race - serialise them.  Calls no hipMalloc / hipFree, and does not synchronise.  The FIRST call on
+ * a device resolves the scratch's address (hipGetSymbolAddress: not a stream operation): make one call outside any
+ * capture before capturing it into a HIP graph. */
 int dfx_resid_update_noalloc(const dfx_geom *g, float *ra, float *rb, const float *A, const float *B, float sa,
                              float sb, float coef_host, const double *coef_dev, int32_t accumulate, double *scal,
                              void *stream);

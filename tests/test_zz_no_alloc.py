@@ -47,6 +47,39 @@ def test_noalloc_resid_update_matches_workspace_variant_twice_second_smaller():
     _both_ways((5, 3, 2, 16, 24, 2), seed=2)         # r = 2
 
 
+def test_noalloc_entry_point_under_hip_graph_capture():
+    """The callers it exists for: after ONE eager call on the device (which resolves the scratch's address with
+    hipGetSymbolAddress - not a stream operation, so not inside a capture), the entry point is captured into a HIP
+    graph and replayed; each replay gives the bits of the workspace variant run eagerly."""
+    from datafusion_amd import _cabi as cabi
+    from datafusion_amd.kernels import HipKernels
+    dims = (6, 4, 5, 64, 128, 4)
+    torch.manual_seed(3)
+    ref, new = HipKernels(*dims, DEV), HipKernels(*dims, DEV)
+    for k in (ref, new):
+        k.new_factored_residual()
+        k.scal[cabi.S_ALPHA] = 0.25
+    A = torch.randn(5, 64, 128, device=DEV)
+    B = torch.randn(6, 4, 16, 32, device=DEV)
+    ref.resid_update(A, B, 0.7, -1.3, 2.0, None, False)
+    new.resid_update_noalloc(A, B, 0.7, -1.3, 2.0, None, False)          # eager warm-up: resolves the symbol
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        new.resid_update_noalloc(A, B, 0.4, 0.9, 0.0, cabi.S_ALPHA, True)     # coefficient 0: state unchanged
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        new.resid_update_noalloc(A, B, 0.4, 0.9, -1.0, cabi.S_ALPHA, True)    # recorded, not executed
+    slots = [cabi.S_RR, cabi.S_RA2, cabi.S_RB2, cabi.S_RAB]
+    for _ in range(3):
+        g.replay()
+        ref.resid_update(A, B, 0.4, 0.9, -1.0, cabi.S_ALPHA, True)
+        torch.cuda.synchronize()
+        assert torch.equal(ref.ra, new.ra) and torch.equal(ref.rb, new.rb)
+        assert torch.equal(ref.scal[slots], new.scal[slots])
+
+
 def test_noalloc_rejects_sizes_beyond_its_scratch():
     from datafusion_amd import _cabi as cabi
     lib = cabi.lib()
