@@ -209,7 +209,8 @@ def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
     x + p = 256 GiB) while the other ranks wait at a barrier; three timed blocks, the median is the anchor and their
     spread is reported.  A failure of the anchor (e.g. not enough free memory) is recorded, not fatal: the efficiency
     against the committed one-GPU figure is always there."""
-    n_t, n_l, n_z, xy, r = WORKLOADS["c3"]
+    strong_wl = os.environ.get("DFX_BENCH_STRONG_WORKLOAD", "c3")     # rehearsals on one GPU use a smaller volume
+    n_t, n_l, n_z, xy, r = WORKLOADS[strong_wl]
     if n_z % world:
         return {"skipped": f"{n_z} z-planes do not split evenly over {world} ranks"}
     steps, warmup = min(a.steps, 20), min(a.warmup, 3)
@@ -218,8 +219,10 @@ def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
     if rank == 0:
         try:
             from datafusion_amd import placement
-            if placement.available_bytes(dev) < 270 * 2 ** 30:
-                raise RuntimeError(f"only {placement.available_bytes(dev) / 2**30:.0f} GiB free on rank 0's GPU")
+            need = int(2 * 4 * n_t * n_l * n_z * xy * xy * 1.03) + (6 << 30)      # x + p, small arrays, workspaces
+            if placement.available_bytes(dev) < need:
+                raise RuntimeError(f"only {placement.available_bytes(dev) / 2**30:.0f} GiB free on rank 0's GPU, the "
+                                   f"whole volume needs {need / 2**30:.0f}")
             one = run("factored", spc=spc, cmos=cmos, grp=None, steps=min(steps, 10), warmup=2, repeats=3)
             blocks = one["block_ms_per_step"]
             anchor = {"iters_per_s": one["its"], "ms_per_step": one["dt"] / one["steps"] * 1e3,
@@ -235,7 +238,8 @@ def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
     res = run(a.residual, spc=spc, cmos=cmos, grp=group, steps=steps, warmup=warmup)
     its = res["its"]
     ok = anchor is not None and "iters_per_s" in anchor
-    out = {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r} (BASELINE configs[2]), {n_z // world} "
+    out = {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r} "
+                       f"({'BASELINE configs[2]' if strong_wl == 'c3' else 'REHEARSAL volume ' + strong_wl}), {n_z // world} "
                        f"z-planes per GPU", "scaling": "strong", "n_gpus": world, "n_elements": res["n_local"] * world,
            "iters_per_s": its, "ms_per_step": res["dt"] / res["steps"] * 1e3, "steps": res["steps"],
            "block_ms_per_step": res["block_ms_per_step"],
@@ -243,8 +247,9 @@ def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
            "kernel_ms": res["kern"], "roofline": roofline(res, a.residual, (None, "none: not profiled"), r=r),
            "comm": res.get("comm"), "placement": res["placement"], "one_gpu_anchor": anchor,
            "strong_scaling_efficiency": (its / (world * anchor["iters_per_s"])) if ok else None,
-           "strong_scaling_efficiency_vs_committed_one_gpu_figure": its / (world * COMMITTED_C3_ONE_GPU_ITS),
-           "committed_one_gpu_iters_per_s": COMMITTED_C3_ONE_GPU_ITS}
+           "strong_scaling_efficiency_vs_committed_one_gpu_figure":
+               its / (world * COMMITTED_C3_ONE_GPU_ITS) if strong_wl == "c3" else None,
+           "committed_one_gpu_iters_per_s": COMMITTED_C3_ONE_GPU_ITS if strong_wl == "c3" else None}
     return out
 
 
@@ -258,7 +263,7 @@ def self_launch(n_gpus: int) -> int:
     import subprocess
     import threading
     found = torch.cuda.device_count()
-    if found < n_gpus:
+    if found < n_gpus and not (found >= 1 and os.environ.get("DFX_BENCH_SHARE_GPU") == "1"):
         sys.stderr.write(f"bench.py --gpus {n_gpus}: needs {n_gpus} GPUs, found {found}\n")
         return 2
     with socket.socket() as sk:
@@ -337,6 +342,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("DFX_BENCH_SHARE_GPU") == "1":
+        # rehearsal of the N-rank control flow on a box with fewer GPUs: ranks share devices (with DFX_BENCH_BACKEND=gloo,
+        # RCCL refuses two ranks on one GPU); the numbers of such a run mean nothing, its one line and exit code do
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     group = None
@@ -344,7 +353,11 @@ def main():
     use_dist = world > 1 or (os.environ.get("DFX_FORCE_COMM") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        backend = os.environ.get("DFX_BENCH_BACKEND", "nccl")             # "nccl" is RCCL; "gloo" only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from datafusion_amd import FusionCG
@@ -457,7 +470,8 @@ def main():
             return None, f"none: {type(e).__name__} reading profiles/{PMC_RECORD}"
 
     # DFX_BENCH_STRONG=1 (with DFX_FORCE_COMM=1): rehearse the strong-scaling leg with one rank on a 1-GPU box
-    want_strong = group is not None and a.workload == "c2" and (world > 1 or os.environ.get("DFX_BENCH_STRONG") == "1")
+    force_strong = os.environ.get("DFX_BENCH_STRONG") == "1"
+    want_strong = group is not None and ((a.workload == "c2" and world > 1) or force_strong)
     # the strong-scaled configs[2] leg first: it is the measurement north_star's scaling target is about, and its
     # one-GPU anchor wants the memory before anything else has used it
     strong = strong_scaling_leg(a, world, rank, dev, group, run, roofline) if want_strong else None

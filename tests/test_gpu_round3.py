@@ -208,6 +208,31 @@ def test_bench_starts_its_own_ranks():
         assert "needs 2 GPUs, found 1" in p.stderr
 
 
+def test_bench_two_rank_control_flow_rehearsal():
+    """The N > 1 control flow of bench.py with TWO real processes: self-launch, the strong-scaling leg (rank 0 runs the
+    one-GPU anchor first while rank 1 waits at the barrier, then both run their halves), the weak-scaled headline, the
+    max-over-ranks timing, one JSON line from rank 0, clean shutdown.  The box has one GPU, so the ranks share it and
+    the group is gloo (staged through the host; RCCL refuses two ranks on one device): the numbers mean nothing, the
+    line, its fields and the exit code do.  Two RCCL ranks on two GPUs remain unverified."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(DFX_BENCH_BACKEND="gloo", DFX_BENCH_SHARE_GPU="1", DFX_BENCH_STRONG="1", DFX_BENCH_STRONG_WORKLOAD="cells")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "3",
+                        "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=280, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["comm"]["world_size"] == 2 and d["comm"]["backend"] == "gloo"
+    assert d["value"] == pytest.approx(2 * d["iters_per_s"])
+    assert "other_residual_mode" in d
+    s = d["config3_strong_scaling"]
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong" and "10 z-planes per GPU" in s["workload"]
+    assert s["comm"]["world_size"] == 2
+    assert "iters_per_s" in s["one_gpu_anchor"], s["one_gpu_anchor"]
+    assert s["strong_scaling_efficiency"] == pytest.approx(s["iters_per_s"] / (2 * s["one_gpu_anchor"]["iters_per_s"]))
+
+
 def test_rank_aware_placement_with_small_chunks_gives_the_same_bits(monkeypatch):
     """datafusion_amd/placement.py end to end on vectors of a few hundred MiB (128 MiB chunks, forced on): vectors mapped
     chunk by chunk through dfx_arena_* behave like torch allocations - same bits as placement="plain" - for two vectors
