@@ -198,25 +198,29 @@ def bench_adam(a, world, rank, dev, group, use_dist):
         dist.destroy_process_group()
 
 
-COMMITTED_C3_ONE_GPU_ITS = 11.1    # profiles/r02_bench_one_rank_rccl_with_config3_strong_leg.json: config 3 whole on one MI355X
+# one MI355X, the whole volume, factored residual (profiles/r03_bench_matrix.txt, r03_whole_gpu_series.txt)
+COMMITTED_ONE_GPU_ITS = {"c3": 11.1, "c4": 11.06}
+BASELINE_CONFIG = {"c3": "BASELINE configs[2]", "c4": "BASELINE configs[3]"}
 
 
-def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
+def strong_scaling_leg(a, world, rank, dev, group, run, roofline, workload="c3", with_anchor=True):
     """N > 1 only, same invocation as the weak-scaled headline: BASELINE.json configs[2] (t512 x l32 x z32 x 256 x 256,
     2^35 elements, 128 GiB per vector - more than one GPU holds with the reference's three vectors) STRONG-scaled:
     32 / N planes per rank, total work fixed.  The one-GPU anchor is measured here too, FIRST (before the sharded
     legs have used the memory): rank 0 alone runs the whole volume on its GPU (it fits with the factored residual:
     x + p = 256 GiB) while the other ranks wait at a barrier; three timed blocks, the median is the anchor and their
     spread is reported.  A failure of the anchor (e.g. not enough free memory) is recorded, not fatal: the efficiency
-    against the committed one-GPU figure is always there."""
-    strong_wl = os.environ.get("DFX_BENCH_STRONG_WORKLOAD", "c3")     # rehearsals on one GPU use a smaller volume
+    against the committed one-GPU figure is always there.
+    workload="c4", with_anchor=False: BASELINE configs[3] (t256 x l16 x z32 x 512 x 512) the same way, against the
+    committed one-GPU figure only (run at N = 8, the GPU count that config names)."""
+    strong_wl = os.environ.get("DFX_BENCH_STRONG_WORKLOAD", workload)     # rehearsals on one GPU use a smaller volume
     n_t, n_l, n_z, xy, r = WORKLOADS[strong_wl]
     if n_z % world:
         return {"skipped": f"{n_z} z-planes do not split evenly over {world} ranks"}
     steps, warmup = min(a.steps, 20), min(a.warmup, 3)
     spc, cmos = synthetic(n_t, n_l, n_z, xy, r)
     anchor = None
-    if rank == 0:
+    if rank == 0 and with_anchor:
         try:
             from datafusion_amd import placement
             need = int(2 * 4 * n_t * n_l * n_z * xy * xy * 1.03) + (6 << 30)      # x + p, small arrays, workspaces
@@ -238,8 +242,9 @@ def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
     res = run(a.residual, spc=spc, cmos=cmos, grp=group, steps=steps, warmup=warmup)
     its = res["its"]
     ok = anchor is not None and "iters_per_s" in anchor
+    committed = COMMITTED_ONE_GPU_ITS.get(strong_wl)
     out = {"workload": f"FusionCG t{n_t} x l{n_l} x z{n_z} x {xy} x {xy}, r={r} "
-                       f"({'BASELINE configs[2]' if strong_wl == 'c3' else 'REHEARSAL volume ' + strong_wl}), {n_z // world} "
+                       f"({BASELINE_CONFIG.get(strong_wl, 'REHEARSAL volume ' + strong_wl)}), {n_z // world} "
                        f"z-planes per GPU", "scaling": "strong", "n_gpus": world, "n_elements": res["n_local"] * world,
            "iters_per_s": its, "ms_per_step": res["dt"] / res["steps"] * 1e3, "steps": res["steps"],
            "block_ms_per_step": res["block_ms_per_step"],
@@ -247,9 +252,8 @@ def strong_scaling_leg(a, world, rank, dev, group, run, roofline):
            "kernel_ms": res["kern"], "roofline": roofline(res, a.residual, (None, "none: not profiled"), r=r),
            "comm": res.get("comm"), "placement": res["placement"], "one_gpu_anchor": anchor,
            "strong_scaling_efficiency": (its / (world * anchor["iters_per_s"])) if ok else None,
-           "strong_scaling_efficiency_vs_committed_one_gpu_figure":
-               its / (world * COMMITTED_C3_ONE_GPU_ITS) if strong_wl == "c3" else None,
-           "committed_one_gpu_iters_per_s": COMMITTED_C3_ONE_GPU_ITS if strong_wl == "c3" else None}
+           "strong_scaling_efficiency_vs_committed_one_gpu_figure": its / (world * committed) if committed else None,
+           "committed_one_gpu_iters_per_s": committed}
     return out
 
 
@@ -475,6 +479,9 @@ def main():
     # the strong-scaled configs[2] leg first: it is the measurement north_star's scaling target is about, and its
     # one-GPU anchor wants the memory before anything else has used it
     strong = strong_scaling_leg(a, world, rank, dev, group, run, roofline) if want_strong else None
+    # BASELINE configs[3] names 8 GPUs: measured in the same invocation when that is the GPU count
+    config4 = (strong_scaling_leg(a, world, rank, dev, group, run, roofline, workload="c4", with_anchor=False)
+               if want_strong and (world == 8 or os.environ.get("DFX_BENCH_CONFIG4") == "1") else None)
     main_res = run(a.residual)
     other = "explicit" if a.residual == "factored" else "factored"
     # the explicit residual needs a third resident 5-D vector: skip that leg where it cannot fit (configs 3 / 4 whole
@@ -525,6 +532,8 @@ def main():
         out["comm"] = main_res["comm"]
     if strong is not None:
         out["config3_strong_scaling"] = strong
+    if config4 is not None:
+        out["config4_strong_scaling"] = config4
     failed = False
     if rank == 0:
         if not a.no_cpu and world == 1:

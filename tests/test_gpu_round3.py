@@ -215,7 +215,8 @@ def test_bench_two_rank_control_flow_rehearsal():
     the group is gloo (staged through the host; RCCL refuses two ranks on one device): the numbers mean nothing, the
     line, its fields and the exit code do.  Two RCCL ranks on two GPUs remain unverified."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(DFX_BENCH_BACKEND="gloo", DFX_BENCH_SHARE_GPU="1", DFX_BENCH_STRONG="1", DFX_BENCH_STRONG_WORKLOAD="cells")
+    env.update(DFX_BENCH_BACKEND="gloo", DFX_BENCH_SHARE_GPU="1", DFX_BENCH_STRONG="1", DFX_BENCH_STRONG_WORKLOAD="cells",
+               DFX_BENCH_CONFIG4="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "3",
                         "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=280, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -231,6 +232,8 @@ def test_bench_two_rank_control_flow_rehearsal():
     assert s["comm"]["world_size"] == 2
     assert "iters_per_s" in s["one_gpu_anchor"], s["one_gpu_anchor"]
     assert s["strong_scaling_efficiency"] == pytest.approx(s["iters_per_s"] / (2 * s["one_gpu_anchor"]["iters_per_s"]))
+    s4 = d["config4_strong_scaling"]          # the BASELINE configs[3] leg of an 8-GPU run (no anchor), same rehearsal volume
+    assert s4["n_gpus"] == 2 and s4["one_gpu_anchor"] is None and s4["iters_per_s"] > 0
 
 
 def test_rank_aware_placement_with_small_chunks_gives_the_same_bits(monkeypatch):
