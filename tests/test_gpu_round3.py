@@ -187,6 +187,26 @@ def test_readme_flow_at_its_stated_size(tmp_path):
     assert e_ho <= 1e-4 + 1e-6 or e_o64 > 1e-4, (e_ho, e_o64)
 
 
+@pytest.mark.parametrize("dims", [(5, 3, 6, 32, 64, 4), (4, 2, 9, 48, 16, 4), (3, 3, 5, 24, 40, 8), (6, 2, 4, 20, 36, 2),
+                                  (3, 2, 3, 18, 30, 3)])
+def test_solver_on_non_square_planes_vs_the_oracle(dims):
+    """X != Y through the whole solver (the reference's baseline() assumes square planes, baseline.py:38, but its CG
+    does not: init_type="random"), both residual representations, fast path (r = 2, 4, 8) and generic path (r = 3),
+    unequal weights, against the eager oracle."""
+    from datafusion_amd import FusionCG
+    n_t, n_l, n_z, X, Y, r = dims
+    g = torch.Generator().manual_seed(1)
+    spc = 0.1 + 0.9 * torch.rand(n_t, n_l, X // r, Y // r, generator=g)
+    cmos = 0.1 + 0.9 * torch.rand(n_z, X, Y, generator=g)
+    w = {"spatial": 0.3, "spectro_temporal": 0.7}
+    xo = O.cg(O.prepare(spc, cmos, weights=w, init_type="random", tol=None), 6, with_loss=False)
+    for residual in ("factored", "explicit"):
+        f = FusionCG(spc, cmos, weights=w, init_type="random", tol=None, device=DEV, residual=residual)
+        assert f.k.plan.fast == (1 if r in (2, 4, 8) else 0)
+        x, _, _ = f(6, return_numpy=False)
+        assert float(O.rel_l2(x.cpu(), xo)) <= TIGHT, (dims, residual)
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus N` as the driver runs it, without a launcher: the parent starts the ranks as child
     processes and passes rank 0's one line through.  One rank here (DFX_FORCE_COMM=1 takes the RCCL path with a
