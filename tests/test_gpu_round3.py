@@ -207,6 +207,18 @@ def test_solver_on_non_square_planes_vs_the_oracle(dims):
         assert float(O.rel_l2(x.cpu(), xo)) <= TIGHT, (dims, residual)
 
 
+def test_sharded_fuzz_three_processes_on_one_gpu():
+    """tools/fuzz_sharded.py, 12 random cases: groups of 2 and 3 ranks (processes sharing cuda:0 over gloo), uneven plane
+    counts, r in {2, 3, 4, 8}, masks, tolerance stops, banded sweeps - CG (factored / explicit, deferred / textbook) and
+    Adam (fused factored / explicit first moment, autograd) with the REAL kernels, each gathered volume against the CPU
+    oracle (100 cases: profiles/r03_fuzz_sharded.txt)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sharded.py"), "--cases", "12", "--seed", "11",
+                        "--port", "29677"], capture_output=True, text=True, timeout=280, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "12 cases, worst rel-L2" in p.stdout and "failed: []" in p.stdout, p.stdout[-2000:]
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus N` as the driver runs it, without a launcher: the parent starts the ranks as child
     processes and passes rank 0's one line through.  One rank here (DFX_FORCE_COMM=1 takes the RCCL path with a

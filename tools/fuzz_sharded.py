@@ -1,0 +1,136 @@
+"""Random geometries through the Z-SHARDED path with the real kernels: three processes share cuda:0 (gloo group, staged
+through the host - RCCL refuses several ranks on one device), groups of 2 and 3 ranks, uneven plane counts, every solver
+variant (CG factored / explicit residual, deferred / textbook x update, banded sweeps; Adam fused with a factored /
+explicit first moment, and the autograd formulation), masks, tolerance stops - each against the CPU oracle on the
+gathered volume.  Not part of the test-suite (a minute); run on a GPU box after touching the sharded schedule, the band
+bookkeeping or the planner.
+
+    python tools/fuzz_sharded.py [--cases 24] [--seed 0]
+"""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD = 3
+
+
+def worker(rank, port, cases, seed, q):
+    sys.path[:0] = [ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from datafusion_amd import FusionAdam, FusionCG
+    from oracle import fusion_oracle as O
+    groups = {2: dist.new_group([0, 1]), 3: dist.new_group([0, 1, 2])}
+    rng = random.Random(seed)
+    worst, failed = 0.0, []
+    for case in range(cases):
+        world = rng.choice([2, 3, 3])
+        r = rng.choice([2, 4, 4, 4, 8, 3])
+        xs = rng.randint(1, 48 // r)
+        n_t, n_l = rng.randint(1, 10), rng.randint(1, 6)
+        n_z = rng.randint(world, 17)
+        xy = xs * r
+        w = {"spatial": rng.choice([0.5, 0.2, 0.8]), "spectro_temporal": rng.choice([0.5, 0.8, 0.2])}
+        mask = rng.random() < 0.3
+        tol = rng.choice([None, None, 3e-3])
+        iters = rng.randint(1, 7)
+        slices = rng.choice([1, 2, 3, "auto"])
+        gen = O.cells_like_inputs if rng.random() < 0.5 else O.synthetic_inputs
+        spc, cmos = gen(n_t, n_l, n_z, xy, r, seed=1000 + case)
+        lr = 1e-2 / (n_t * n_l * n_z * xy * xy)
+        variants = [("cg", dict(residual=res, defer_x=d)) for res in ("factored", "explicit") for d in (True, False)]
+        variants += [("adam", dict(moment1="factored")), ("adam", dict(moment1="explicit")), ("adam", dict(fused=False))]
+        if rank >= world:
+            continue                               # not a member of this case's group
+        grp = groups[world]
+        ref = {}
+        diverged = [False]
+        if rank == 0:
+            try:
+                pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=tol, mask_noise=mask)
+                ref["cg"] = (O.cg(pb, iters, with_loss=False).numpy(), pb.curr_iter)
+                pb = O.prepare(spc, cmos, weights=w, init_type="baseline", tol=None, mask_noise=mask)
+                ref["adam"] = (O.adam(pb, lr, 3, non_neg=mask).numpy(), 3)
+            except AssertionError:
+                diverged[0] = True          # fusion.py:448 on a degenerate input (e.g. a z-column masked to zero -> 0/0)
+        dist.broadcast_object_list(diverged, src=0, group=grp)
+        if diverged[0]:
+            # the reference raises "Conjugate gradient diverged": so must every rank of the sharded product
+            raised = 0
+            for res in ("factored", "explicit"):
+                try:
+                    FusionCG(spc, cmos, weights=w, init_type="baseline", tol=tol, device="cuda:0", mask_noise=mask,
+                             group=grp, comm_slices=slices, residual=res)(iters, return_numpy=False)
+                except AssertionError:
+                    raised += 1
+            flags = [None] * world
+            dist.all_gather_object(flags, raised, group=grp)
+            if rank == 0:
+                ok = all(v == 2 for v in flags)
+                print(f"case {case}: {world} ranks, t{n_t} l{n_l} z{n_z} {xy}x{xy} r{r} mask={mask} tol={tol}: the oracle "
+                      f"diverges (fusion.py:448); AssertionError on every rank, both residual modes: {ok}", flush=True)
+                if not ok:
+                    failed.append((case, "no AssertionError", flags))
+            continue
+        errs = {}
+        for kind, kw in variants:
+            if kind == "cg":
+                f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=tol, device="cuda:0", mask_noise=mask,
+                             group=grp, comm_slices=slices, **kw)
+                x, _, _ = f(iters, return_numpy=False)
+            else:
+                f = FusionAdam(spc, cmos, weights=w, init_type="baseline", tol=None, device="cuda:0", mask_noise=mask,
+                               group=grp, comm_slices=slices, **kw)
+                x, _, _ = f(lr=lr, max_iterations=3, non_neg=mask, return_numpy=False)
+            parts = [None] * world
+            dist.all_gather_object(parts, (f.z_range, x.detach().cpu().numpy(), f.curr_iter), group=grp)
+            if rank == 0:
+                full = np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0])], axis=2)
+                name = kind + "/" + "/".join(f"{k}={v}" for k, v in kw.items())
+                errs[name] = O.rel_l2(full, ref[kind][0])
+                its = {p[2] for p in parts}
+                if its != {ref[kind][1]}:
+                    errs[name + " ITERATIONS"] = float("inf")
+            del f, x
+        if rank == 0:
+            bad = {k: v for k, v in errs.items() if not v <= 2e-5}
+            worst = max(worst, max(errs.values()))
+            print(f"case {case}: {world} ranks, t{n_t} l{n_l} z{n_z} {xy}x{xy} r{r} mask={mask} tol={tol} iters={iters}"
+                  f"->{ref['cg'][1]} slices={slices} max err {max(errs.values()):.2e}" + (f"  FAIL {bad}" if bad else ""),
+                  flush=True)
+            if bad:
+                failed.append((case, bad))
+    dist.barrier()
+    if rank == 0:
+        print(f"{cases} cases, worst rel-L2 vs the oracle {worst:.3e}, failed: {failed}", flush=True)
+        q.put(failed)
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=24)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--port", type=int, default=29671)
+    a = ap.parse_args()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, a.port, a.cases, a.seed, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join()
+    codes = [p.exitcode for p in procs]
+    failed = q.get(timeout=5) if all(c == 0 for c in codes) else [("exit codes", codes)]
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()
