@@ -211,7 +211,9 @@ def test_sharded_fuzz_three_processes_on_one_gpu():
     """tools/fuzz_sharded.py, 12 random cases: groups of 2 and 3 ranks (processes sharing cuda:0 over gloo), uneven plane
     counts, r in {2, 3, 4, 8}, masks, tolerance stops, banded sweeps - CG (factored / explicit, deferred / textbook) and
     Adam (fused factored / explicit first moment, autograd) with the REAL kernels, each gathered volume against the CPU
-    oracle (100 cases: profiles/r03_fuzz_sharded.txt)."""
+    oracle (100 cases: profiles/r03_fuzz_sharded.txt).  Seed 11 holds a case (t5 l4 z2 16x16 r8) where ONE element of
+    10 240 has a gradient of the size of Adam's eps, so its first step differs by 0.26 lr between HIP and the oracle
+    (2.2e-5 in rel-L2, sharded or not): the tool then checks sharded == unsharded (1e-7) and north_star's 1e-4."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sharded.py"), "--cases", "12", "--seed", "11",
                         "--port", "29677"], capture_output=True, text=True, timeout=280, env=env)

@@ -79,7 +79,7 @@ def worker(rank, port, cases, seed, q):
                 if not ok:
                     failed.append((case, "no AssertionError", flags))
             continue
-        errs = {}
+        errs, fulls = {}, {}
         for kind, kw in variants:
             if kind == "cg":
                 f = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=tol, device="cuda:0", mask_noise=mask,
@@ -95,6 +95,7 @@ def worker(rank, port, cases, seed, q):
                 full = np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0])], axis=2)
                 name = kind + "/" + "/".join(f"{k}={v}" for k, v in kw.items())
                 errs[name] = O.rel_l2(full, ref[kind][0])
+                fulls[name] = full
                 its = {p[2] for p in parts}
                 if its != {ref[kind][1]}:
                     errs[name + " ITERATIONS"] = float("inf")
@@ -106,7 +107,26 @@ def worker(rank, port, cases, seed, q):
                   f"->{ref['cg'][1]} slices={slices} max err {max(errs.values()):.2e}" + (f"  FAIL {bad}" if bad else ""),
                   flush=True)
             if bad:
-                failed.append((case, bad))
+                # above the tight bar: the same call unsharded (this rank alone) tells what the distance is.  Adam turns
+                # a gradient that is zero up to rounding into a step of +-lr, so on a small volume HIP and the oracle can
+                # differ by a few 1e-5 with or without shards; a SHARDING error shows as sharded != unsharded
+                real = {}
+                for kind, kw in variants:
+                    name = kind + "/" + "/".join(f"{k}={v}" for k, v in kw.items())
+                    if name not in bad:
+                        continue
+                    if kind == "cg":
+                        x1, _, _ = FusionCG(spc, cmos, weights=w, init_type="baseline", tol=tol, device="cuda:0",
+                                            mask_noise=mask, **kw)(iters)
+                    else:
+                        x1, _, _ = FusionAdam(spc, cmos, weights=w, init_type="baseline", tol=None, device="cuda:0",
+                                              mask_noise=mask, **kw)(lr=lr, max_iterations=3, non_neg=mask)
+                    e1, e2 = O.rel_l2(x1, ref[kind][0]), O.rel_l2(fulls[name], x1)
+                    print(f"      {name}: unsharded vs oracle {e1:.3e}, sharded vs unsharded {e2:.3e}", flush=True)
+                    if not (bad[name] <= 1e-4 and e2 <= 2e-6):        # north_star's bar, and the shards add nothing
+                        real[name] = (bad[name], e1, e2)
+                if real:
+                    failed.append((case, real))
     dist.barrier()
     if rank == 0:
         print(f"{cases} cases, worst rel-L2 vs the oracle {worst:.3e}, failed: {failed}", flush=True)
