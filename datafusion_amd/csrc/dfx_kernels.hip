@@ -10,7 +10,8 @@
 //     cross-lane adds over the lanes holding the other rows of the block (r = 4: l^16, l^32);
 //   * the CG residual is never a 5-D array by default: r = ra[z,x,y] + rb[t,l,x/r,y/r] (k_resid_*).
 // No LDS tile and no barrier in the streaming loop; LDS is only used for the per-workgroup scalar partials.
-// r outside {2, 4, 8} (or Y % 4 != 0) takes the generic kernels.
+// r = 3, 5, 6, 7, 10, 12, 16 run the same kernels over a general tile (LaneMap<0>: block sums through a wave-private
+// LDS tile, accesses through the L2); any other r, or Y % 4 != 0, takes the generic kernels.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -75,10 +76,23 @@ struct Geo {
     long long N;   // M*S
     int M;         // nT*nL
     int nZ, X, Y, Xs, Ys, r;
-    int WT;        // wave tiles per plane (fast path): ceil(nblk / BW), BW = 64, 16, 4 blocks per wave for r = 2, 4, 8
+    int WT;        // wave tiles per plane (fast path): ceil(nblk / BW), BW = 64, 16, 4 blocks per wave for r = 2, 4, 8;
+                   // general r (LaneMap<0>): Xs * gTPR
+    int gL;        // general r: lanes (float4) per tile row, 0 when r has no such tile; tile = r rows x 4 gL columns
+    int gTPR;      // general r: tiles per band of r rows = ceil(Y / (4 gL))
     int nblk;      // r x r blocks per plane = Xs*Ys
     int zs;        // planes per z-chunk of the plan in use (<= the kernel's ZC); set by the entry points
 };
+
+// General r (LaneMap<0>): a wave covers one band of r rows x TC = 4 L columns, one float4 per lane, with L the largest
+// multiple of r / gcd(4, r) such that r L <= 64 lanes - then TC is a multiple of r and a tile holds whole blocks.
+// r = 3: 3 x 84 (63 lanes), 5: 5 x 40 (50), 6: 6 x 36 (54), 7: 7 x 28 (49), 10: 10 x 20 (50), 12: 12 x 12 (36), 16: 16 x 16 (64);
+// 0 (no tile: r = 1, 9, 11, 13, 14, 15, > 16) sends the geometry to the generic kernels.
+int general_lanes_per_row(int r) {
+    if (r < 3 || r > 64) return 0;
+    const int g = (r % 4 == 0) ? 4 : (r % 2 == 0 ? 2 : 1), q = r / g;
+    return (64 / r) / q * q;
+}
 
 int make_geo(const dfx_geom *g, Geo *o) {
     if (!g) return fail(DFX_EINVAL, "geom is NULL");
@@ -101,16 +115,22 @@ int make_geo(const dfx_geom *g, Geo *o) {
     o->N = o->S * M;
     if (o->S > 0x7fffffffLL) return fail(DFX_EINVAL, "one (t,l) slab must stay below 2^31 elements");
     o->nblk = o->Xs * o->Ys;
-    {
+    o->gL = o->gTPR = 0;
+    if (o->r == 2 || o->r == 4 || o->r == 8) {
         const int bw = o->r == 2 ? 64 : (o->r == 8 ? 4 : 16);   // LaneMap<R>::BW
         o->WT = (o->nblk + bw - 1) / bw;
+    } else {
+        o->gL = general_lanes_per_row(o->r);
+        o->gTPR = o->gL ? (o->Y + 4 * o->gL - 1) / (4 * o->gL) : 0;
+        o->WT = o->Xs * o->gTPR;
     }
     return 0;
 }
 
-// r in {2, 4, 8} with Y a multiple of 4 (implied for r = 4, 8): every plane row is 16-byte aligned and a float4
-// never straddles a block row (r = 4, 8) or covers exactly two blocks (r = 2).  See LaneMap<R>.
-bool fast_ok(const Geo &q) { return (q.r == 2 || q.r == 4 || q.r == 8) && (q.Y % 4) == 0; }
+// Y a multiple of 4 (every plane row 16-byte aligned) and r in {2, 4, 8} - a float4 never straddles a block row
+// (r = 4, 8) or covers exactly two blocks (r = 2), LaneMap<R> - or an r with a general tile (LaneMap<0>: 3, 5, 6, 7, 10,
+// 12, 16).
+bool fast_ok(const Geo &q) { return (q.r == 2 || q.r == 4 || q.r == 8 || q.gL > 0) && (q.Y % 4) == 0; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -186,6 +206,30 @@ __device__ __forceinline__ void st4s(float *p, f4 v) {
     st4(p, v);
 #endif
 }
+// the lane-mapped kernels pick the policy per lane map: the r = 2, 4, 8 tiles read and write whole 128 / 256 / 512 B row
+// segments and stream them non-temporally; the general-r tile (LaneMap<0>) has row segments of 48 - 336 B that do not end
+// on sector boundaries, and non-temporal stores of partial sectors cost it 1.5 - 2.7x (measured at C2 size, r = 3 / 6 /
+// 12 / 16: 5.58 / 8.01 / 13.67 / 4.85 ms non-temporal against 3.67 / 3.82 / 5.02 / 3.22 ms through the L2; non-temporal loads
+// with cached stores: 4.59 / 5.06 / 8.15 / 5.63 ms).  What did NOT matter: the LDS block sums (same times without them),
+// and handing each XCD a contiguous range of tile groups so that shared lines meet in one L2 (+-1 %).
+#ifndef DFX_GEN_NT_LD
+#define DFX_GEN_NT_LD 0
+#endif
+#ifndef DFX_GEN_NT_ST
+#define DFX_GEN_NT_ST 0
+#endif
+template <bool NT>
+__device__ __forceinline__ f4 ld4t(const float *p) { return NT ? ld4s(p) : ld4(p); }
+template <bool NT>
+__device__ __forceinline__ void st4t(float *p, f4 v) {
+    if (NT) st4s(p, v);
+    else st4(p, v);
+}
+template <int R>
+struct Stream {
+    static constexpr bool LD = R == 0 ? (DFX_GEN_NT_LD != 0) : true;   // true: as DFX_NT says
+    static constexpr bool ST = R == 0 ? (DFX_GEN_NT_ST != 0) : true;
+};
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float dot4(f4 a, f4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
@@ -243,6 +287,73 @@ struct LaneMap {
     }
 };
 
+// General r (R = 0: r = 3, 5, 6, 7, 10, 12, 16; see general_lanes_per_row).  A float4 may straddle two blocks (never
+// three: r >= 3), so the block sums go through a wave-private LDS tile instead of shuffles: every lane stores its
+// z-summed float4, the lanes of tile row 0 add the r rows of their four columns (r ds_read_b128), then one lane per block
+// adds its r column sums (r ds_read_b32).  LDS operations of one wave execute in order; the wavefront-scope fences
+// keep the compiler from moving them across each other.  Everything else (u accumulators, ra in registers, 16 B
+// streaming accesses) is the fast path's.
+template <>
+struct LaneMap<0> {
+    bool act;
+    long long off2;   // element offset of the lane's float4 inside a plane
+    int bi;           // small-space index (inside a plane of Xs x Ys) of the block under the float4's first element
+    int cut;          // how many of the four elements lie in that block (the rest in block bi + 1); >= 4: all
+    int lds;          // this lane's float4 in the wave's LDS tile (floats)
+    int TC, r, rows;  // tile width (floats), block size, tile rows (= r)
+    int csum;         // >= 0: this lane adds the r rows of columns [csum, csum + 4) of the tile
+    int vb, vcol;     // vb >= 0: this lane adds block vb of the small plane from column sums [vcol, vcol + r)
+    __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
+        const int L = q.gL;
+        r = rows = q.r;
+        TC = 4 * L;
+        const int dx = lane / L, j = lane - dx * L;
+        const int xb = wt / q.gTPR, tc = wt - xb * q.gTPR;
+        const int col = tc * TC + 4 * j;
+        act = wt < q.WT && dx < r && col < q.Y;
+        off2 = (long long)(xb * r + dx) * q.Y + col;
+        const int yb = col / r;
+        bi = xb * q.Ys + yb;
+        cut = r - (col - yb * r);
+        lds = dx * TC + 4 * j;
+        const int yt = min(TC, q.Y - tc * TC);       // live columns of this tile: a multiple of 4 and of r
+        const int apr = yt >> 2, nb = yt / r;         // active lanes per row, blocks in the tile
+        csum = (dx == 0 && j < apr) ? 4 * j : -1;
+        const int o = dx * apr + j;                   // ordinal among the active lanes: the first nb of them sum a block
+        vb = (act && o < nb) ? xb * q.Ys + (tc * TC) / r + o : -1;
+        vcol = o * r;
+    }
+    __device__ __forceinline__ void vstore(f4 s4, float *vrow, int lane) const {
+        __shared__ __attribute__((aligned(16))) float tile[DFX_WAVES][512];   // r x TC floats (<= 340) + TC column sums
+        float *t = tile[threadIdx.x >> 6];
+        float *cs = t + rows * TC;
+        *reinterpret_cast<f4 *>(t + lds) = s4;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (csum >= 0) {
+            f4 c = *reinterpret_cast<const f4 *>(t + csum);
+            for (int d = 1; d < rows; ++d) c += *reinterpret_cast<const f4 *>(t + d * TC + csum);
+            *reinterpret_cast<f4 *>(cs + csum) = c;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (vb >= 0) {
+            float s = cs[vcol];
+            for (int d = 1; d < r; ++d) s += cs[vcol + d];
+            vrow[vb] = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next slab's stores stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ f4 bload(const float *brow) const {
+        const float b0 = brow[bi];
+        const float b1 = cut < 4 ? brow[bi + 1] : b0;
+        return (f4){b0, cut > 1 ? b0 : b1, cut > 2 ? b0 : b1, cut > 3 ? b0 : b1};
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // Fast sweep: x += alpha p ; p = r + beta p ; u(p), v(p), ||p||^2, ||x||^2, <x,p>   (MODE XP)
 // ------------------------------------------------------------------------------------------
@@ -293,17 +404,17 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
                 if (j < cnt) {
                     const long long i = base + (long long)(g + j) * a.q.P;
                     if (MODE == DFX_SWEEP_PROJECT) {
-                        xv[j] = ld4s(a.x + i);
+                        xv[j] = ld4t<Stream<R>::LD>(a.x + i);
                     } else if (MODE == DFX_SWEEP_XP) {
-                        xv[j] = ld4s(a.x + i);
-                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
-                        pv[j] = ld4s(a.p + i);
+                        xv[j] = ld4t<Stream<R>::LD>(a.x + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4t<Stream<R>::LD>(a.r + i);
+                        pv[j] = ld4t<Stream<R>::LD>(a.p + i);
                     } else if (MODE == DFX_SWEEP_P) {
-                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
-                        pv[j] = ld4s(a.p + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4t<Stream<R>::LD>(a.r + i);
+                        pv[j] = ld4t<Stream<R>::LD>(a.p + i);
                     } else {  // PINIT
-                        xv[j] = ld4s(a.x + i);
-                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
+                        xv[j] = ld4t<Stream<R>::LD>(a.x + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4t<Stream<R>::LD>(a.r + i);
                     }
                 }
             }
@@ -318,18 +429,18 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
                     } else if (MODE == DFX_SWEEP_XP) {
                         const f4 xn = xv[j] + fa * pv[j];
                         pn = rv[j] + fb * pv[j];
-                        st4s(a.x + i, xn);
-                        st4s(a.p + i, pn);
+                        st4t<Stream<R>::ST>(a.x + i, xn);
+                        st4t<Stream<R>::ST>(a.p + i, pn);
                         xx += dot4(xn, xn);
                         xp += dot4(xn, pn);
                         pp += dot4(pn, pn);
                     } else if (MODE == DFX_SWEEP_P) {
                         pn = rv[j] + fb * pv[j];
-                        st4s(a.p + i, pn);
+                        st4t<Stream<R>::ST>(a.p + i, pn);
                         pp += dot4(pn, pn);
                     } else {
                         pn = rv[j];
-                        st4s(a.p + i, pn);
+                        st4t<Stream<R>::ST>(a.p + i, pn);
                         xx += dot4(xv[j], xv[j]);
                         xp += dot4(xv[j], pn);
                         pp += dot4(pn, pn);
@@ -438,7 +549,7 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int m0, int m1, 
                 if (HAS_IN) {
                     const long long base = (long long)mm * a.q.S + off;
 #pragma unroll
-                    for (int k = 0; k < ZN; ++k) iv[u][k] = ld4s(a.in + base + (long long)k * a.q.P);
+                    for (int k = 0; k < ZN; ++k) iv[u][k] = ld4t<Stream<R>::LD>(a.in + base + (long long)k * a.q.P);
                 }
             }
         }
@@ -453,7 +564,7 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int m0, int m1, 
                     {
                         f4 o = av[k] + (HAS_MASK ? mk[k] * b[u] : b[u]);
                         if (HAS_IN) o += iv[u][k];
-                        st4s(a.out + base + (long long)k * a.q.P, o);
+                        st4t<Stream<R>::ST>(a.out + base + (long long)k * a.q.P, o);
                         rr += dot4(o, o);
                     }
                 }
@@ -596,9 +707,9 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
             for (int j = 0; j < GS; ++j) {
                 if (j < cnt) {
                     const long long i = base + (long long)(g + j) * a.q.P;
-                    xv[j] = ld4s(a.x + i);
-                    if (!M1F) e1[j] = ld4s(a.m1 + i);
-                    e2[j] = ld4s(a.m2 + i);
+                    xv[j] = ld4t<Stream<R>::LD>(a.x + i);
+                    if (!M1F) e1[j] = ld4t<Stream<R>::LD>(a.m1 + i);
+                    e2[j] = ld4t<Stream<R>::LD>(a.m2 + i);
                 }
             }
 #pragma unroll
@@ -613,9 +724,9 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
                         if (HAS_MASK) e1[j] *= mk[k];
                     }
                     const f4 xn = adam_elem4<M1F>(xv[j], gr, e1[j], e2[j], a);
-                    st4s(a.x + i, xn);
-                    if (!M1F) st4s(a.m1 + i, e1[j]);
-                    st4s(a.m2 + i, e2[j]);
+                    st4t<Stream<R>::ST>(a.x + i, xn);
+                    if (!M1F) st4t<Stream<R>::ST>(a.m1 + i, e1[j]);
+                    st4t<Stream<R>::ST>(a.m2 + i, e2[j]);
                     const f4 d = xn - xv[j];
                     dd += dot4(d, d);
                     xx += dot4(xn, xn);
@@ -1507,13 +1618,14 @@ int check_plan(const Geo &q, const dfx_plan *pl) {
 bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 bool aligned8(const void *p) { return (((uintptr_t)p) & 7) == 0; }   // small-space rows: float2 access when r = 2
 
-// the fast kernels exist for zc in {4, 8} x r in {2, 4, 8}; check_plan / fast_ok admit nothing else
+// the fast kernels exist for zc in {4, 8} x r in {2, 4, 8, general (LaneMap<0>)}; check_plan / fast_ok admit nothing else
 #define DFX_DISPATCH_R(ZCV, r, ...)                                        \
     do {                                                                   \
         constexpr int ZC_ = ZCV;                                           \
         if ((r) == 2) { constexpr int R_ = 2; __VA_ARGS__; }               \
         else if ((r) == 4) { constexpr int R_ = 4; __VA_ARGS__; }          \
-        else { constexpr int R_ = 8; __VA_ARGS__; }                        \
+        else if ((r) == 8) { constexpr int R_ = 8; __VA_ARGS__; }          \
+        else { constexpr int R_ = 0; __VA_ARGS__; }                        \
     } while (0)
 #define DFX_DISPATCH_ZC_R(zc, r, ...)                                      \
     do {                                                                   \

@@ -271,17 +271,23 @@ def test_sliced_sweep_is_bitwise_identical():
                                   (70, 3, 5, 8, 64, 4), (2, 2, 3, 12, 20, 4), (3, 2, 5, 4, 4, 4), (2, 3, 2, 36, 100, 4),
                                   (2, 2, 3, 12, 20, 2), (3, 1, 2, 16, 24, 8), (2, 2, 2, 9, 15, 3), (2, 2, 2, 10, 6, 2),
                                   (7, 3, 5, 6, 132, 2), (2, 3, 9, 24, 40, 8), (5, 3, 7, 64, 128, 2), (5, 3, 7, 64, 128, 8),
-                                  (70, 2, 4, 2, 4, 2), (3, 2, 3, 8, 8, 8)])
+                                  (70, 2, 4, 2, 4, 2), (3, 2, 3, 8, 8, 8),
+                                  # general block sizes (LaneMap<0>): one tile, ragged last tile in y, several bands, the
+                                  # widest tiles, lanes of three tile rows summing blocks (r = 3), a one-block wave (r = 16)
+                                  (2, 2, 2, 9, 12, 3), (3, 2, 5, 12, 96, 3), (2, 3, 9, 15, 180, 3), (2, 2, 3, 10, 60, 5),
+                                  (3, 1, 7, 18, 48, 6), (2, 2, 4, 14, 56, 7), (2, 1, 3, 20, 40, 10), (2, 2, 5, 24, 36, 12),
+                                  (3, 2, 9, 32, 80, 16), (5, 3, 6, 120, 120, 6), (2, 2, 2, 9, 18, 9)])
 def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     """Every 5-D kernel against torch float64 formulas on shapes the solver tests cannot reach (X != Y, one wave
     tile, inactive waves in the last workgroup, fewer slabs than workgroups, ragged z-chunks, block rows that wrap inside
-    a wave, a plane smaller than a wave; r = 2, 4, 8 with Y % 4 == 0 take the fast kernels, everything else the generic)."""
+    a wave, a plane smaller than a wave; r = 2, 4, 8 and - through the general tile - 3, 5, 6, 7, 10, 12, 16 with
+    Y % 4 == 0 take the fast kernels, everything else the generic ones)."""
     from datafusion_amd import _cabi as cabi
     from datafusion_amd.kernels import HipKernels
     torch.manual_seed(2)
     n_t, n_l, n_z, X, Y, r = dims
     k = HipKernels(n_t, n_l, n_z, X, Y, r, DEV)
-    assert k.plan.fast == (1 if r in (2, 4, 8) and Y % 4 == 0 else 0)
+    assert k.plan.fast == (1 if r in (2, 4, 8, 3, 5, 6, 7, 10, 12, 16) and Y % 4 == 0 else 0)
     x, rr, p = (torch.randn(k.shape, device=DEV) for _ in range(3))
     al, be = 0.37, -0.61
     k.scal[cabi.S_ALPHA], k.scal[cabi.S_BETA] = al, be

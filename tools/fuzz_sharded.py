@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORLD = 3
 
 
-def worker(rank, port, cases, seed, q):
+def worker(rank, port, cases, seed, q, general_r=False):
     sys.path[:0] = [ROOT]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
@@ -32,8 +32,10 @@ def worker(rank, port, cases, seed, q):
     worst, failed = 0.0, []
     for case in range(cases):
         world = rng.choice([2, 3, 3])
-        r = rng.choice([2, 4, 4, 4, 8, 3])
+        r = rng.choice([3, 5, 6, 7, 10, 12, 16] if general_r else [2, 4, 4, 4, 8, 3])
         xs = rng.randint(1, 48 // r)
+        if general_r:
+            xs = 4 * rng.randint(1, max(1, 24 // r))      # Y = xs r a multiple of 4: the general-r tile (LaneMap<0>)
         n_t, n_l = rng.randint(1, 10), rng.randint(1, 6)
         n_z = rng.randint(world, 17)
         xy = xs * r
@@ -139,10 +141,11 @@ def main():
     ap.add_argument("--cases", type=int, default=24)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--port", type=int, default=29671)
+    ap.add_argument("--general-r", action="store_true", help="r in {3, 5, 6, 7, 10, 12, 16} with Y % 4 == 0 only")
     a = ap.parse_args()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, a.port, a.cases, a.seed, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=worker, args=(r, a.port, a.cases, a.seed, q, a.general_r)) for r in range(WORLD)]
     for p in procs:
         p.start()
     for p in procs:
