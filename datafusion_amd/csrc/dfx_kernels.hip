@@ -212,6 +212,9 @@ __device__ __forceinline__ void st4s(float *p, f4 v) {
 // 12 / 16: 5.58 / 8.01 / 13.67 / 4.85 ms non-temporal against 3.67 / 3.82 / 5.02 / 3.22 ms through the L2; non-temporal loads
 // with cached stores: 4.59 / 5.06 / 8.15 / 5.63 ms).  What did NOT matter: the LDS block sums (same times without them),
 // and handing each XCD a contiguous range of tile groups so that shared lines meet in one L2 (+-1 %).
+#ifndef DFX_GEN_ZB
+#define DFX_GEN_ZB 4      // DFX_ZB of the general tile (LaneMap<0>)
+#endif
 #ifndef DFX_GEN_NT_LD
 #define DFX_GEN_NT_LD 0
 #endif
@@ -386,8 +389,11 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
     // the ZN live planes go in groups of DFX_ZB (loads issued together, then updated and stored); the LAST group takes
     // the remainder too (ZN = 5 -> 2 + 3, 7 -> 2 + 2 + 3), so that no group runs with fewer loads in flight than the
     // others (5 as 2 + 2 + 1 cost three group latencies for five planes: 87 % of the per-plane rate of 4 or 8)
-    constexpr int NG = (ZN / DFX_ZB) > 0 ? ZN / DFX_ZB : 1;
-    constexpr int GS = (2 * DFX_ZB - 1) < ZN ? (2 * DFX_ZB - 1) : ZN;     // largest group
+    // the general tile leaves lanes idle (36 - 63 of 64): four planes per group keep as many loads in flight (measured at
+    // C2 size, r = 3 / 6 / 7 / 12 / 16: 3.39 / 3.73 / 2.95 / 4.52 / 3.15 ms against 3.67 / 3.82 / 3.03 / 5.02 / 3.22 with two)
+    constexpr int ZB = R == 0 ? DFX_GEN_ZB : DFX_ZB;
+    constexpr int NG = (ZN / ZB) > 0 ? ZN / ZB : 1;
+    constexpr int GS = (2 * ZB - 1) < ZN ? (2 * ZB - 1) : ZN;     // largest group
     for (int m = m0; m < m1; m += ms) {
         const long long base = (long long)m * a.q.S + off;
         f4 s4 = {0.f, 0.f, 0.f, 0.f};
@@ -396,8 +402,8 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
         if (FACT) rb4 = L.bload(a.rb + (long long)m * a.q.Ps);
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            const int g = gi * DFX_ZB;
-            const int cnt = (gi == NG - 1) ? ZN - g : DFX_ZB;
+            const int g = gi * ZB;
+            const int cnt = (gi == NG - 1) ? ZN - g : ZB;
             f4 xv[GS], rv[GS], pv[GS];
 #pragma unroll
             for (int j = 0; j < GS; ++j) {
