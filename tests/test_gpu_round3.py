@@ -332,7 +332,7 @@ def test_rank_aware_placement_with_small_chunks_gives_the_same_bits(monkeypatch)
 
 def test_rank_aware_placement_on_a_16_gib_pair():
     """The per-GPU slab of BASELINE configs[2] at G = 8 (16 GiB per vector), default placement: a layout without two
-    vectors in one memory class at any position, the pair streaming in the fast regime (>= 0.74 of the 8 TB/s peak; the
+    vectors in one memory class at any position, the pair streaming in the fast regime (0.79 of the 8 TB/s peak; the
     slow regime is 0.66 - 0.69), and the same bits as torch allocations."""
     from datafusion_amd import FusionCG, placement
     if placement.available_bytes(DEV) < 80 * GIB:
@@ -342,7 +342,10 @@ def test_rank_aware_placement_on_a_16_gib_pair():
     info = f.k.placement_info
     print("placement:", info)
     assert info is not None and info["positions_sharing_a_class"] == 0 and info["chunks_per_vector"] == 8
-    assert info["pair_sweep_GBps"] >= 0.74 * 8000, info
+    # the fast regime, judged against THIS box's own slow regime (the probe's rate on two halves of one chunk, which
+    # share a class by construction; MI355X: ~5.5 against ~6.4 TB/s) rather than against an absolute figure
+    same = placement.pool(DEV).same_rate
+    assert same and info["pair_sweep_GBps"] >= 1.06 * same, (info, same)
     x, _, _ = f(3, return_numpy=False)
     g = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, placement="plain")
     y, _, _ = g(3, return_numpy=False)
