@@ -56,6 +56,7 @@ SIGNATURES = {
                              _i32, _i32, _i32, _P],
     "dfx_lerp": [_P, _P, _i64, _d, _P],
     "dfx_adam_apply": [_P, _P, _P, _P, _i64, _d, _d, _d, _d, _i32, _i32, _i32, _P, _P, _P],
+    "dfx_adam_apply_project": [_G, _PL, _P, _P, _P, _P, _d, _d, _d, _d, _i32, _i32, _P, _P, _P, _P, _P],
     "dfx_adam_prep": [_P, _P, _P, _P, _P, _i64, _P, _P, _P, _i64, _P, _P, _i64, _d, _d, _d, _P, _P, _P],
     "dfx_reduce_u": [_G, _PL, _P, _P, _P, _P, _P],
     "dfx_reduce_v": [_G, _PL, _P, _P, _i64, _i64, _P],

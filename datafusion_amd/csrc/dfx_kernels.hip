@@ -647,6 +647,7 @@ struct AdamArgs {
     int steps, cpb;
     int c_lo, c_hi;   // chunk range of THIS launch (a full step is [0, cpb)), as in SweepArgs
     int row0;         // first row of `part` this launch writes
+    const float *grad;   // GRAD kernels (dfx_adam_apply_project): the explicit gradient; A, B, mask, m1a, m1b unused
 };
 
 // FAST: the hardware square root and reciprocal (1 ulp each; v_sqrt_f32 flushes denormal inputs, harmless while
@@ -656,6 +657,20 @@ struct AdamArgs {
 // generic kernel.
 template <bool M1F, bool FAST>
 __device__ __forceinline__ float adam_elem(float x, float g, float &m1, float &m2, const AdamArgs &a) {
+    if (!FAST) {
+        // DfxAdam's arithmetic, spelled out so that it does not depend on which kernel it is inlined into (the
+        // compiler's choice of fused multiply-adds differed between k_adam_apply and the lane-mapped kernel by one ulp):
+        // the roundings of torch's own sequence - lerp_ as fma(w, g - m1, m1); mul_(beta2) rounded, then addcmul_ as
+        // fma(value * g, g, .); sqrt, scale, + eps; addcdiv_ as fma(-step_size, m1 / denom, x)
+#pragma clang fp contract(off)
+        if (!M1F) m1 = __builtin_fmaf(a.omb1, g - m1, m1);
+        const float m2b = a.b2 * m2;
+        m2 = __builtin_fmaf(a.omb2 * g, g, m2b);
+        const float denom = __fsqrt_rn(m2) * a.inv_sqrt_bc2 + a.eps;
+        float xn = __builtin_fmaf(-a.step_size, __fdiv_rn(m1, denom), x);
+        if (a.non_neg) xn = fmaxf(xn, 0.f);               // fusion.py:344-346
+        return xn;
+    }
     if (!M1F) m1 = m1 + a.omb1 * (g - m1);                // exp_avg.lerp_(grad, 1 - beta1); M1F: m1 is already new
     m2 = a.b2 * m2 + a.omb2 * (g * g);                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     float xn;
@@ -690,7 +705,7 @@ __device__ __forceinline__ f4 adam_elem4(f4 x, f4 g, f4 &m1, f4 &m2, const AdamA
 // loaded, updated and stored at a time.  (Measured at C2, factored first moment, with the hardware sqrt / rcp: 2 planes
 // 2.70 ms, 3: 2.78, 4: 2.80, 8: 2.87, 1: 3.80; whole slabs in two register sets in ping-pong, the round-1 loop, 2.87;
 // with the IEEE sqrt / division sequences 2 planes take 2.85: both changes are needed.)
-template <int ZC, int R, bool HAS_MASK, bool M1F, int ZN>
+template <int ZC, int R, bool HAS_MASK, bool M1F, int ZN, bool GRAD = false>
 __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &L, int m0, int m1e, int gz,
                                               long long off, const f4 (&av)[ZC], const f4 (&mk)[ZC],
                                               const f4 (&m1av)[ZC], f4 (&uacc)[ZC], float *vbase, int lane,
@@ -699,7 +714,8 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
     constexpr int GS = (2 * DFX_ADAM_ZB - 1) < ZN ? (2 * DFX_ADAM_ZB - 1) : ZN;   // takes the remainder
     for (int m = m0; m < m1e; m += gz) {
         const long long base = (long long)m * a.q.S + off;
-        const f4 b4 = L.bload(a.B + (long long)m * a.q.Ps);
+        f4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (!GRAD) b4 = L.bload(a.B + (long long)m * a.q.Ps);
         f4 mb4 = {0.f, 0.f, 0.f, 0.f};
         if (M1F) mb4 = L.bload(a.m1b + (long long)m * a.q.Ps);
         f4 s4 = {0.f, 0.f, 0.f, 0.f};
@@ -708,12 +724,13 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
         for (int gi = 0; gi < NG; ++gi) {
             const int g = gi * DFX_ADAM_ZB;
             const int cnt = (gi == NG - 1) ? ZN - g : DFX_ADAM_ZB;
-            f4 xv[GS], e1[GS], e2[GS];
+            f4 xv[GS], e1[GS], e2[GS], gv[GRAD ? GS : 1];
 #pragma unroll
             for (int j = 0; j < GS; ++j) {
                 if (j < cnt) {
                     const long long i = base + (long long)(g + j) * a.q.P;
                     xv[j] = ld4t<Stream<R>::LD>(a.x + i);
+                    if (GRAD) gv[j] = ld4t<Stream<R>::LD>(a.grad + i);
                     if (!M1F) e1[j] = ld4t<Stream<R>::LD>(a.m1 + i);
                     e2[j] = ld4t<Stream<R>::LD>(a.m2 + i);
                 }
@@ -723,13 +740,15 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
                 if (j < cnt) {
                     const int k = g + j;
                     const long long i = base + (long long)k * a.q.P;
-                    f4 gr = av[k] + b4;
+                    f4 gr = GRAD ? gv[GRAD ? j : 0] : av[k] + b4;
                     if (HAS_MASK) gr *= mk[k];
                     if (M1F) {
                         e1[j] = m1av[k] + mb4;
                         if (HAS_MASK) e1[j] *= mk[k];
                     }
-                    const f4 xn = adam_elem4<M1F>(xv[j], gr, e1[j], e2[j], a);
+                    // GRAD: DfxAdam's step - torch's arithmetic bit for bit (IEEE sqrt and division), like k_adam_apply
+                    const f4 xn = GRAD ? adam_elem4<false, false>(xv[j], gr, e1[j], e2[j], a)
+                                       : adam_elem4<M1F>(xv[j], gr, e1[j], e2[j], a);
                     st4t<Stream<R>::ST>(a.x + i, xn);
                     if (!M1F) st4t<Stream<R>::ST>(a.m1 + i, e1[j]);
                     st4t<Stream<R>::ST>(a.m2 + i, e2[j]);
@@ -747,7 +766,7 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
     }
 }
 
-template <int ZC, int R, bool HAS_MASK, bool M1F>
+template <int ZC, int R, bool HAS_MASK, bool M1F, bool GRAD = false>
 __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(const AdamArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = blockIdx.x * DFX_WAVES + wave;
@@ -766,7 +785,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
             mk[k] = (f4){1.f, 1.f, 1.f, 1.f};
             m1av[k] = (f4){0.f, 0.f, 0.f, 0.f};
             if (k < zcnt) {
-                av[k] = ld4(a.A + off + (long long)k * a.q.P);
+                if (!GRAD) av[k] = ld4(a.A + off + (long long)k * a.q.P);
                 if (HAS_MASK) mk[k] = ld4(a.mask + off + (long long)k * a.q.P);
                 if (M1F) m1av[k] = ld4(a.m1a + off + (long long)k * a.q.P);
             }
@@ -780,7 +799,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
 #define DFX_ZN_CASE(n)                                                                                          \
     case n:                                                                                                     \
         if constexpr (n <= ZC)                                                                                  \
-            adam_chunk<ZC, R, HAS_MASK, M1F, n>(a, L, m0, m1e, gz, off, av, mk, m1av, uacc, vbase, lane, ddd, dxx); \
+            adam_chunk<ZC, R, HAS_MASK, M1F, n, GRAD>(a, L, m0, m1e, gz, off, av, mk, m1av, uacc, vbase, lane, ddd, dxx); \
         break;
             switch (zcnt) {
                 DFX_ZN_CASE(1) DFX_ZN_CASE(2) DFX_ZN_CASE(3) DFX_ZN_CASE(4)
@@ -2100,6 +2119,31 @@ int dfx_adam_apply(float *x, const float *grad, float *m1, float *m2, int64_t n,
     hipLaunchKernelGGL(k_adam_apply<DFX_APPLY_UNROLL>, dim3(nb), dim3(256), 0, st, x, grad, m1, m2, (long long)n, a);
     DFX_LAUNCH_CHECK("dfx_adam_apply");
     return fold(part, nb, 2, scal + DFX_S_ADAM_DD, 1.0, st, scal + DFX_S_TOL);
+}
+
+int dfx_adam_apply_project(const dfx_geom *g, const dfx_plan *pl, float *x, const float *grad, float *m1, float *m2,
+                           double lr, double beta1, double beta2, double eps, int32_t step, int32_t flags, double *scal,
+                           float *u_part, float *v_part, double *part, void *stream) {
+    Geo q;
+    if (int rc = make_geo(g, &q)) return rc;
+    if (int rc = check_plan(q, pl)) return rc;
+    if (!pl->fast) return fail(DFX_EPLAN, "dfx_adam_apply_project: lane-mapped plans only (use dfx_adam_apply + dfx_sweep)");
+    q.zs = pl->zs;
+    if (!x || !grad || !m1 || !m2 || !scal || !u_part || !v_part || !part)
+        return fail(DFX_EINVAL, "dfx_adam_apply_project: NULL buffer");
+    if (step < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1) || !(eps >= 0))
+        return fail(DFX_EINVAL, "dfx_adam_apply_project: step >= 1, betas in [0, 1) and eps >= 0 required");
+    if (!aligned16(x) || !aligned16(grad) || !aligned16(m1) || !aligned16(m2) || !aligned16(u_part) || !aligned8(v_part))
+        return fail(DFX_EALIGN, "dfx_adam_apply_project: x, grad, m1, m2, u_part must be 16-byte, v_part 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamArgs a{x, m1, m2, nullptr, nullptr, nullptr, nullptr, nullptr, u_part, v_part, part, (float)beta1, (float)beta2,
+               (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
+               (flags & DFX_ADAM_NONNEG) ? 1 : 0, q, pl->steps, pl->cpb, 0, pl->cpb, 0, grad};
+    dim3 grid((q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
+    DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false, false, true>), grid, block, 0, st, a));
+    DFX_LAUNCH_CHECK("dfx_adam_apply_project");
+    return 0;   // u, v, ADAM_DD, ADAM_XX, TOL: dfx_post_sweep(DFX_POST_U | DFX_POST_V | DFX_POST_FOLD_ADAM)
 }
 
 int dfx_adam_prep(const float *u, const float *cmos, const float *cmask, float *A, float *m1a, int64_t n_u,

@@ -225,6 +225,7 @@ class Fusion:
 
     def _project(self, x) -> None:
         """u(x) -> k.u (local planes), v(x) -> k.v (summed over shards)."""
+        self._uv_of = None
         self.k.sweep(cabi.SWEEP_PROJECT, x)
         self.comm.sum_(self.k.v)
 
@@ -531,7 +532,10 @@ class _FusionLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, fusion, mask_grad):
-        fusion._project(x.detach())
+        # k.u, k.v may already hold the projections of exactly this x: the optimizer step that produced it left them
+        # (DfxAdam with a projector, dfx_adam_apply_project) and nothing has written x since (torch's version counter)
+        if getattr(fusion, "_uv_of", None) != (x.data_ptr(), x._version):
+            fusion._project(x.detach())
         k = fusion.k
         du = k.diff_scale(fusion._cmos_loc, k.u, fusion._cmask_loc if fusion.mask_noise else None, 1.0)
         dv = k.diff_scale(fusion.spc, k.v, fusion._smask_f if fusion.mask_noise else None, 1.0)
@@ -563,7 +567,7 @@ class FusionAdam(Fusion):
     torch.optim.Adam.step()."""
 
     def __init__(self, *args, fused: bool = True, betas=(0.9, 0.999), adam_eps: float = 1e-8,
-                 moment1: str = "factored", **kwargs):
+                 moment1: str = "factored", project_in_step: bool = True, **kwargs):
         """moment1="factored" (default, fused=True only): exp_avg is linear in the gradients, which are all of the
         form mask * (A[z,x,y] + B[t,l,x/r,y/r]), so it is kept as two small arrays advanced by dfx_lerp and never
         stored as a 5-D vector: x and exp_avg_sq are the only volumes read and written (4N words per iteration).
@@ -572,6 +576,8 @@ class FusionAdam(Fusion):
             raise ValueError("moment1 must be 'factored' or 'explicit'")
         self.fused = fused
         self.moment1 = moment1
+        self.project_in_step = bool(project_in_step)     # fused=False only: see _run_autograd
+        self._uv_of = None
         super().__init__(*args, **kwargs)
         self.betas, self.adam_eps = betas, adam_eps
         self._m1 = self._m2 = self._m1a = self._m1b = self._gA = self._gB = None
@@ -679,7 +685,11 @@ class FusionAdam(Fusion):
         if self._auto_bufs is None and self.k.reserved_left() >= 2:
             self._auto_bufs = (self.k.new_vector(), self.k.new_vector())       # laid out next to x by memory class
         bufs = {self.x: self._auto_bufs} if self._auto_bufs is not None else None
-        optimizer = self.k.adam_optimizer([self.x], lr, self.betas, self.adam_eps, non_neg, bufs)     # DfxAdam
+        # project_in_step: the optimizer step also leaves u(x), v(x) of the stepped volume (dfx_adam_apply_project), so
+        # the next iteration's loss needs no projection pass of its own: 8N instead of 9N words per iteration
+        proj = {self.x: self.k} if self.project_in_step else None
+        optimizer = self.k.adam_optimizer([self.x], lr, self.betas, self.adam_eps, non_neg, bufs, proj)     # DfxAdam
+        self._uv_of = None
         for i in range(max_iterations):
             self.curr_iter += 1
             optimizer.zero_grad()
@@ -688,6 +698,9 @@ class FusionAdam(Fusion):
             loss = spatial_loss + spectro_temporal_loss
             loss.backward()
             optimizer.step()                                                    # + clamp (fusion.py:344-346)
+            if self.x in getattr(optimizer, "projected", ()):
+                self.comm.sum_(self.k.v)                                        # the RD partials of the stepped volume
+                self._uv_of = (self.x.data_ptr(), self.x._version)
             self._last_norms = optimizer.last_sq_norms                          # ||x - prev_x||^2, ||x||^2 (this shard)
             tolerance = None
             if self.tol is not None:                                            # fusion.py:348

@@ -359,15 +359,35 @@ class HipKernels:
                                0 if smask is None else smask.numel(), cabi.ptr(B), cabi.ptr(m1b), B.numel(), w1, w2,
                                lerp_weight, cabi.ptr(self.scal), cabi.ptr(self.part), self._stream()), "dfx_adam_prep")
 
+    @_on_device
+    def adam_apply_project(self, x, grad, m1, m2, lr, beta1, beta2, eps, step: int, non_neg: bool) -> bool:
+        """torch.optim.Adam's step on the explicit gradient (what DfxAdam does) fused with the projections of the
+        stepped x: u(x) -> self.u, local v partial -> self.v, ADAM_DD / ADAM_XX -> scal (dfx_adam_apply_project +
+        dfx_post_sweep).  Lane-mapped plans only: returns False (nothing done) on a generic plan."""
+        if not self.plan.fast:
+            return False
+        self._chk(x, grad, m1, m2)
+        assert x.numel() == grad.numel() == m1.numel() == m2.numel() == self.N
+        g, pl = self._g()
+        self._last_slices = 1
+        cabi.check(self._timed("apply_project", self.lib.dfx_adam_apply_project, g, pl, cabi.ptr(x), cabi.ptr(grad),
+                               cabi.ptr(m1), cabi.ptr(m2), lr, beta1, beta2, eps, step,
+                               cabi.ADAM_NONNEG if non_neg else 0, cabi.ptr(self.scal), cabi.ptr(self.u_part),
+                               cabi.ptr(self.v_part), cabi.ptr(self.part), self._stream()), "dfx_adam_apply_project")
+        self.post_sweep(cabi.POST_U | cabi.POST_V | cabi.POST_FOLD_ADAM)
+        return True
+
     def reserved_left(self) -> int:
         return len(self._reserved)
 
     @staticmethod
-    def adam_optimizer(params, lr, betas, eps, non_neg, moment_buffers=None):
+    def adam_optimizer(params, lr, betas, eps, non_neg, moment_buffers=None, projectors=None):
         """The optimizer of the autograd formulation (fusion.py:325): torch.optim.Adam's update as one launch;
-        moment_buffers: {parameter: (exp_avg, exp_avg_sq)} placed by the caller (reserve_vectors) or None."""
+        moment_buffers: {parameter: (exp_avg, exp_avg_sq)} placed by the caller (reserve_vectors) or None;
+        projectors: {parameter: HipKernels} - the step of that parameter also leaves u, v of the stepped volume."""
         from .optim import DfxAdam
-        return DfxAdam(params, lr=lr, betas=betas, eps=eps, non_neg=non_neg, moment_buffers=moment_buffers)
+        return DfxAdam(params, lr=lr, betas=betas, eps=eps, non_neg=non_neg, moment_buffers=moment_buffers,
+                       projectors=projectors)
 
     @_on_device
     def lerp(self, m, g, weight: float) -> None:

@@ -25,11 +25,15 @@ from . import _cabi as cabi
 
 class DfxAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, non_neg: bool = False,
-                 n_blocks: int = 0, moment_buffers=None):
+                 n_blocks: int = 0, moment_buffers=None, projectors=None):
         """moment_buffers: optional {parameter: (exp_avg, exp_avg_sq)} of caller-placed tensors shaped like the
         parameter (FusionAdam passes vectors laid out by memory class next to x, datafusion_amd/placement.py: the
         step's seven streams run at 0.78 of the HBM peak spread over two or more classes, 0.72 inside one); they are
-        zeroed when first used.  Default: torch.zeros_like."""
+        zeroed when first used.  Default: torch.zeros_like.
+        projectors: optional {parameter: HipKernels of the 5-D volume the parameter is}: the step of such a parameter
+        runs as dfx_adam_apply_project - the same update, in the sweep's lane-mapped structure, which also leaves
+        u(x), v(x) of the STEPPED volume in the HipKernels object (FusionAdam's next forward then needs no projection
+        pass); `projected` holds the parameters the last step() handled that way."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("DfxAdam: lr, eps >= 0 and betas in [0, 1) required")
         # the param-group keys of torch.optim.Adam as well (fixed to what this optimizer implements), so that a
@@ -42,6 +46,8 @@ class DfxAdam(torch.optim.Optimizer):
         self.n_blocks = int(n_blocks)
         self.last_sq_norms = None   # device tensor (2,) float64: ||dx||^2, ||x||^2 over the parameters of the last step()
         self._scratch = {}          # device -> (scal, part): launch scratch, not optimizer state
+        self._projectors = dict(projectors or {})
+        self.projected = set()      # parameters whose last step also projected the stepped volume
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -51,6 +57,7 @@ class DfxAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = cabi.lib()
         total = None
+        self.projected = set()
         for group in self.param_groups:
             if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
                 raise cabi.DfxError("DfxAdam implements Adam with weight_decay=0, amsgrad=False, maximize=False only")
@@ -78,6 +85,14 @@ class DfxAdam(torch.optim.Optimizer):
                         st[key] = st[key].to(device=p.device, dtype=torch.float32).contiguous()
                 step = int(st["step"]) + 1                    # tensor (torch.optim.Adam's) or number
                 st["step"] = st["step"] + 1 if isinstance(st["step"], torch.Tensor) else step
+                k = self._projectors.get(p)
+                if k is not None and p.numel() == k.N and p.device == k.device and k.adam_apply_project(
+                        p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], group["betas"][0], group["betas"][1],
+                        group["eps"], step, non_neg):
+                    self.projected.add(p)
+                    norms = k.scal[cabi.S_ADAM_DD:cabi.S_ADAM_XX + 1]
+                    total = norms.clone() if total is None else total + norms.to(total.device)
+                    continue
                 if p.device not in self._scratch:
                     self._scratch[p.device] = (torch.zeros(cabi.NSCAL, dtype=torch.float64, device=p.device),
                                                torch.empty(cabi.EW_MAXBLOCKS * cabi.NPART, dtype=torch.float64,

@@ -230,6 +230,16 @@ int dfx_adam_step_chunks(const dfx_geom *g, const dfx_plan *pl, float *x, float 
 int dfx_adam_apply(float *x, const float *grad, float *m1, float *m2, int64_t n, double lr, double beta1,
                    double beta2, double eps, int32_t step, int32_t flags, int32_t n_blocks, double *scal, double *part,
                    void *stream);
+/* The same optimizer.step() (fusion.py:342, on the explicit x.grad of fusion.py:338) for a parameter that IS the 5-D
+ * volume of geometry g, fused with the projections the NEXT iteration's loss() starts with (T, S, D, R of fusion.py:
+ * 226-232 on the stepped x): the step runs in the sweep's lane-mapped structure (x, grad, m1, m2 read, x, m1, m2
+ * written: 7N words) and leaves u_part, v_part and the ADAM_DD / ADAM_XX partials exactly as dfx_adam_step(...,
+ * DFX_ADAM_NOFOLD) does - finish with dfx_post_sweep(DFX_POST_U | DFX_POST_V | DFX_POST_FOLD_ADAM).  Saves the N-word
+ * projection pass of the following forward.  Arithmetic: dfx_adam_apply's (IEEE square root and division; eps = 0
+ * allowed).  flags: DFX_ADAM_NONNEG.  Fast (lane-mapped) plans only, else DFX_EPLAN. */
+int dfx_adam_apply_project(const dfx_geom *g, const dfx_plan *pl, float *x, const float *grad, float *m1, float *m2,
+                           double lr, double beta1, double beta2, double eps, int32_t step, int32_t flags, double *scal,
+                           float *u_part, float *v_part, double *part, void *stream);
 
 /* The small-space half of one fused Adam iteration in ONE launch (fusion.py:332-338: loss(), and what
  * loss.backward() does on the cmos- and spc-sized arrays):

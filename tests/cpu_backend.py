@@ -31,8 +31,8 @@ class _CpuAdam(torch.optim.Adam):
 
 class CpuStandIn:
     @staticmethod
-    def adam_optimizer(params, lr, betas, eps, non_neg, moment_buffers=None):
-        return _CpuAdam(params, lr, betas, eps, non_neg)
+    def adam_optimizer(params, lr, betas, eps, non_neg, moment_buffers=None, projectors=None):
+        return _CpuAdam(params, lr, betas, eps, non_neg)      # no fused projection: `projected` stays absent
 
     def reserved_left(self):
         return 0

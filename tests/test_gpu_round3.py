@@ -400,6 +400,69 @@ def test_dfx_adam_state_round_trips_with_torch_optim_adam():
         assert O.rel_l2(ob2.state[q]["exp_avg_sq"].cpu(), oa2.state[p]["exp_avg_sq"].cpu()) <= 1e-6
 
 
+@pytest.mark.parametrize("dims", [(6, 4, 5, 32, 64, 4), (3, 2, 9, 24, 24, 2), (4, 3, 7, 16, 48, 8), (3, 2, 6, 24, 36, 3),
+                                  (2, 3, 3, 14, 56, 7)])
+def test_adam_apply_project_equals_apply_then_project(dims):
+    """dfx_adam_apply_project (DfxAdam's step in the sweep's lane-mapped structure, fused with the projections of the
+    stepped volume) against dfx_adam_apply followed by a projection sweep: x, exp_avg, exp_avg_sq bit for bit (the same
+    IEEE arithmetic element by element), u, v and the two norms to rounding; clamp on and off, eps = 0 included."""
+    from datafusion_amd import _cabi as cabi
+    from datafusion_amd.kernels import HipKernels
+    from datafusion_amd.optim import DfxAdam
+    torch.manual_seed(5)
+    n_t, n_l, n_z, X, Y, r = dims
+    k = HipKernels(n_t, n_l, n_z, X, Y, r, DEV)
+    assert k.plan.fast == 1
+    for non_neg, eps in ((False, 1e-8), (True, 0.0)):
+        x0 = torch.randn(k.shape, device=DEV)
+        runs = []
+        for proj in (None, "k"):
+            x = torch.nn.Parameter(x0.clone())
+            opt = DfxAdam([x], lr=1e-2, eps=eps, non_neg=non_neg, projectors={x: k} if proj else None)
+            for step in range(3):
+                x.grad = torch.sin(x0 * (step + 1.5))
+                opt.step()
+                assert (x in opt.projected) == bool(proj)
+            st = opt.state[x]
+            runs.append((x.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), opt.last_sq_norms.clone()))
+        for a, b in zip(runs[0][:3], runs[1][:3]):
+            assert torch.equal(a, b)
+        assert torch.allclose(runs[0][3], runs[1][3], rtol=1e-6)
+        xd = runs[1][0].double()
+        u = xd.sum((0, 1))
+        v = xd.sum(2).reshape(n_t, n_l, X // r, r, Y // r, r).sum((3, 5))
+        assert O.rel_l2(k.u.cpu(), u.cpu()) <= 1e-6 and O.rel_l2(k.v.cpu(), v.cpu()) <= 1e-6
+
+
+@pytest.mark.parametrize("mask", [False, True])
+def test_autograd_adam_projects_inside_the_optimizer_step(mask):
+    """FusionAdam(fused=False): with project_in_step (default) the optimizer step leaves u(x), v(x) of the stepped volume
+    and the next forward skips its projection pass - the same iterate bit for bit as with the separate pass, both
+    within the tight bar of the oracle; a write to x between two steps (torch's version counter) forces a fresh
+    projection."""
+    from datafusion_amd import FusionAdam
+    spc, cmos = O.cells_like_inputs(6, 4, 5, 32, 4, seed=3)
+    lr = 1e-2 / (6 * 4 * 5 * 32 * 32)
+    xo = O.adam(O.prepare(spc, cmos, weights=W, init_type="baseline", tol=None, mask_noise=mask), lr, 4, non_neg=True)
+    out = []
+    for proj in (True, False):
+        f = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, fused=False, mask_noise=mask,
+                       project_in_step=proj)
+        x, _, _ = f(lr=lr, max_iterations=4, non_neg=True, return_numpy=False)
+        assert (f._uv_of is not None) == proj
+        assert float(O.rel_l2(x.detach().cpu(), xo)) <= TIGHT
+        out.append(x.detach().clone())
+    assert torch.equal(out[0], out[1])
+    # x written behind the cache's back: the forward must project again
+    f = FusionAdam(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV, fused=False, mask_noise=mask)
+    f(lr=lr, max_iterations=1, non_neg=True, return_numpy=False)
+    with torch.no_grad():
+        f.x.mul_(2.0)
+    l1, l2 = f.loss_autograd()
+    m1, m2 = f.loss()
+    assert np.allclose([float(l1.detach()), float(l2.detach())], [float(m1), float(m2)], rtol=1e-6)
+
+
 def test_fused_adam_rejects_eps_zero():
     """The fused 5-D kernels use the hardware sqrt / reciprocal, which need eps > 0 to keep the quotient finite where
     exp_avg_sq is denormal: refused with a clear error instead of returning inf."""
