@@ -42,6 +42,7 @@ int main() {
         if (dfx_bcast(&g, &pl, nf, nf, nf, nf, nf, 1, 1, 1, nd, nd, nd, nullptr) == 0) ++bad;
         if (dfx_adam_step(&g, &pl, nf, nf, nf, nf, nf, nf, 1e-3, 0.9, 0.999, 1e-8, 1, 0, nd, nf, nf, nd, nullptr) == 0) ++bad;
         if (dfx_adam_step_factored(&g, &pl, nf, nf, nf, nf, nf, nf, nf, 1e-3, 0.9, 0.999, 1e-8, 1, 0, nd, nf, nf, nd, nullptr) == 0) ++bad;
+        if (dfx_adam_apply_project(&g, &pl, nf, nf, nf, nf, 1e-3, 0.9, 0.999, 1e-8, 1, 0, nd, nf, nf, nd, nullptr) == 0) ++bad;
         if (dfx_reduce_u(&g, &pl, nf, nf, nd, nd, nullptr) == 0) ++bad;
         if (dfx_reduce_v(&g, &pl, nf, nf, 0, 1, nullptr) == 0) ++bad;
         if (dfx_baseline_init(&g, nf, nf, nf, 1, nd, nd, nd, nullptr) == 0) ++bad;
