@@ -8,7 +8,11 @@ The timed loop is run twice in one invocation: with the library's default factor
 `roofline`) and with the residual as an explicit third 5-D vector (`other_residual_mode`); --single times one only.
 N = 1: BASELINE.json configs[1] (t256 x l16 x z16 x 128 x 128, r = 4).  N > 1: weak scaling, the
 same 16-plane slab per GPU (nZ = 16 N), z-sharded, one RCCL all-reduce of the spc-sized RD partial
-plus two scalar all-reduces per iteration.  Rank 0 prints ONE JSON line.
+plus two scalar all-reduces per iteration.  Rank 0 prints ONE JSON line.  `--gpus N` without a launcher starts its own
+N ranks (self_launch); the N > 1 line also carries BASELINE configs[2] strong-scaled (and configs[3] at N = 8).
+Environment knobs, for rehearsals on a box with one GPU only: DFX_FORCE_COMM=1 (issue the collectives on a one-rank
+group), DFX_BENCH_STRONG=1 (run the strong-scaling leg whatever N), DFX_BENCH_STRONG_WORKLOAD=<name> (its volume),
+DFX_BENCH_CONFIG4=1, DFX_BENCH_BACKEND=gloo with DFX_BENCH_SHARE_GPU=1 (several ranks on one device).
 """
 import argparse
 import json
