@@ -165,7 +165,7 @@ def bench_adam(a, world, rank, dev, group, use_dist):
     n_t, n_l, nz_gpu, xy, r = WORKLOADS[a.workload]
     spc, cmos = synthetic(n_t, n_l, nz_gpu * world, xy, r)
     f = FusionAdam(spc, cmos, weights={"spatial": 0.5, "spectro_temporal": 0.5}, init_type="baseline", tol=None,
-                   device=dev, group=group, fused=(a.method == "adam"), moment1=a.moment1)
+                   device=dev, group=group, fused=(a.method == "adam"), moment1=a.moment1, placement=a.placement)
     n_local = f.k.N
     f(lr=1e-8, max_iterations=a.warmup, return_numpy=False)
     main_kernel = "adamf" if a.moment1 == "factored" else "adam"

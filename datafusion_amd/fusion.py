@@ -601,10 +601,14 @@ class FusionAdam(Fusion):
         return (2 if self.moment1 == "factored" else 3) if self.fused else 3
 
     def _placement_min_bytes(self):
-        # the optimizer step of the autograd formulation (dfx_adam_apply: seven streams over four arrays) gains from
-        # spreading its arrays over the memory classes already at C2's 4 GiB (0.72 -> 0.78 of peak, 145 -> 157 it/s);
-        # the two-vector sweeps only from 8 GiB on (measured: tools/exp_c2_min_vector.sh)
-        return None if self.fused else (1 << 30)
+        # the FLAT optimizer step of the autograd formulation (dfx_adam_apply: seven streams over four arrays) gains from
+        # spreading its arrays over the memory classes already at C2's 4 GiB (0.72 -> 0.78 of peak); the lane-mapped
+        # projecting step that replaces it on fast plans (dfx_adam_apply_project) does not (C2: 4.87 ms placed against
+        # 4.78 / 5.00 ms from torch, two runs each) and the 0.25 s of probes would cost more than 40 iterations; the
+        # two-vector sweeps gain only from 8 GiB on (measured: tools/exp_c2_min_vector.sh)
+        if self.fused or (self.project_in_step and getattr(getattr(self.k, "plan", None), "fast", 0)):
+            return None
+        return 1 << 30
 
     def loss_autograd(self, mask_grad: bool = False):
         return _FusionLossFn.apply(self.x, self, mask_grad)
