@@ -96,7 +96,14 @@ class HipKernels:
         self._reserved, self.placement_info = [], None
         if mode != "rank" or n < 2 or 4 * self.N < (placement.MIN_VECTOR_BYTES if min_bytes is None else min_bytes):
             return
-        got = placement.pool(self.device).alloc_vectors(n, self.N)
+        try:
+            got = placement.pool(self.device).alloc_vectors(n, self.N)
+        except (cabi.DfxError, torch.cuda.OutOfMemoryError) as e:
+            # the layout is an optimisation: if the virtual-memory API is not usable here (driver, granularity, address
+            # space) or memory ran out while classifying, give the pool's chunks back and take torch allocations
+            placement.trim(self.device)
+            self.placement_info = {"failed": f"{type(e).__name__}: {e}"}
+            return
         if got is None:
             return
         vecs, self.placement_info = got

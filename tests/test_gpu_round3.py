@@ -328,6 +328,18 @@ def test_rank_aware_placement_with_small_chunks_gives_the_same_bits(monkeypatch)
     placement.trim()
     torch.cuda.empty_cache()
     assert pool.arena is None and torch.cuda.mem_get_info()[0] >= free0 - (1 << 30)
+    # the layout is an optimisation: when the virtual-memory API fails, the solve runs on torch allocations
+    from datafusion_amd import _cabi as cabi
+
+    def broken(self, n_more):
+        raise cabi.DfxError("dfx_arena_create failed (code 801): hipMemCreate: operation not supported")
+
+    monkeypatch.setattr(placement.DevicePool, "_create", broken)
+    fz = FusionCG(spc, cmos, weights=W, init_type="baseline", tol=None, device=DEV)
+    assert "failed" in fz.k.placement_info and not fz.k._reserved
+    xz, _, _ = fz(6)
+    assert np.array_equal(xz, ref["factored"])
+    del fz
 
 
 def test_rank_aware_placement_on_a_16_gib_pair():
