@@ -10,12 +10,13 @@
 //     cross-lane adds over the lanes holding the other rows of the block (r = 4: l^16, l^32);
 //   * the CG residual is never a 5-D array by default: r = ra[z,x,y] + rb[t,l,x/r,y/r] (k_resid_*).
 // No LDS tile and no barrier in the streaming loop; LDS is only used for the per-workgroup scalar partials.
-// r = 3, 5, 6, 7, 10, 12, 16 run the same kernels over a general tile (LaneMap<0>: block sums through a wave-private
-// LDS tile, accesses through the L2); any other r, or Y % 4 != 0, takes the generic kernels.
+// r = 3, 5, 7, 16 run the same kernels over a general tile (LaneMap<0>: block sums through a wave-private LDS tile,
+// accesses through the L2); any other r, or Y % 4 != 0, takes the generic kernels (k_gen_sweep4 / k_gen_sweep2 + k_gen_proj_v2).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -86,10 +87,15 @@ struct Geo {
 
 // General r (LaneMap<0>): a wave covers one band of r rows x TC = 4 L columns, one float4 per lane, with L the largest
 // multiple of r / gcd(4, r) such that r L <= 64 lanes - then TC is a multiple of r and a tile holds whole blocks.
-// r = 3: 3 x 84 (63 lanes), 5: 5 x 40 (50), 6: 6 x 36 (54), 7: 7 x 28 (49), 10: 10 x 20 (50), 12: 12 x 12 (36), 16: 16 x 16 (64);
-// 0 (no tile: r = 1, 9, 11, 13, 14, 15, > 16) sends the geometry to the generic kernels.
+// r = 3: 3 x 84 (63 lanes), 5: 5 x 40 (50), 7: 7 x 28 (49), 16: 16 x 16 (64) [6: 6 x 36, 10: 10 x 20, 12: 12 x 12 exist but lose
+// to the generic kernels]; 0 sends the geometry to the generic kernels.
 int general_lanes_per_row(int r) {
-    if (r < 3 || r > 64) return 0;
+    static const bool off = getenv("DFX_NO_GENERAL_TILE") != nullptr;   // measurement knob: send every such r to the generic kernels
+    if (off) return 0;
+    // the tile is used where it beats the generic kernels (flat float4 sweep + a separate v pass, any r): measured on
+    // the C2 volume, tile / generic, r = 3: 3.39 / 3.73 ms, 5: 3.42 / 3.67, 7: 2.96 / 3.29, 16: 3.16 / 3.82 - but
+    // 6: 3.74 / 3.64, 10: 3.71 / 3.62, 12: 4.52 / 3.64 (few lanes per tile row, short row segments)
+    if (!(r == 3 || r == 5 || r == 7 || r == 16)) return 0;
     const int g = (r % 4 == 0) ? 4 : (r % 2 == 0 ? 2 : 1), q = r / g;
     return (64 / r) / q * q;
 }
@@ -128,8 +134,7 @@ int make_geo(const dfx_geom *g, Geo *o) {
 }
 
 // Y a multiple of 4 (every plane row 16-byte aligned) and r in {2, 4, 8} - a float4 never straddles a block row
-// (r = 4, 8) or covers exactly two blocks (r = 2), LaneMap<R> - or an r with a general tile (LaneMap<0>: 3, 5, 6, 7, 10,
-// 12, 16).
+// (r = 4, 8) or covers exactly two blocks (r = 2), LaneMap<R> - or an r with a general tile (LaneMap<0>: 3, 5, 7, 16).
 bool fast_ok(const Geo &q) { return (q.r == 2 || q.r == 4 || q.r == 8 || q.gL > 0) && (q.Y % 4) == 0; }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -290,7 +295,7 @@ struct LaneMap {
     }
 };
 
-// General r (R = 0: r = 3, 5, 6, 7, 10, 12, 16; see general_lanes_per_row).  A float4 may straddle two blocks (never
+// General r (R = 0: r = 3, 5, 7, 16; see general_lanes_per_row).  A float4 may straddle two blocks (never
 // three: r >= 3), so the block sums go through a wave-private LDS tile instead of shuffles: every lane stores its
 // z-summed float4, the lanes of tile row 0 add the r rows of their four columns (r ds_read_b128), then one lane per block
 // adds its r column sums (r ds_read_b32).  LDS operations of one wave execute in order; the wavefront-scope fences
@@ -918,40 +923,207 @@ __device__ __forceinline__ float gen_resid(const float *r, const float *ra, cons
     return ra[j] + rb[m * q.Ps + (long long)(xi / q.r) * q.Ys + yi / q.r];
 }
 
+// The generic sweep (any r, any Y): the fast path's loop structure with scalar lanes.  A thread owns DFX_GEN_K positions
+// j of the slab (consecutive threads, consecutive j: 256 B per wave-instruction) and walks the slabs m = bz, bz + gz, ...;
+// what depends on j only - the block under it, its ra - is worked out once per tile instead of per element (the first
+// form, k_gen_sweep, spent its time in 64-bit divisions: 3.5 TB/s), and u accumulates in registers (fp32 for 64 slabs,
+// then into a double), so the separate projection pass for u (one more read of the volume) is gone.  v keeps its own
+// pass (k_gen_proj_v).  Grid: (tile slots, gz); u_part has gz rows.
+#define DFX_GEN_K 4
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gen_sweep(float *x, const float *r, const float *ra, const float *rb,
-                                                   float *p, const double *scal, Geo q, double *part) {
-    const long long n = q.N;
+__global__ __launch_bounds__(256) void k_gen_sweep2(float *x, const float *r, const float *ra, const float *rb, float *p,
+                                                    const double *scal, Geo q, int n_tiles, float *u_part,
+                                                    double *part) {
+    const int gz = gridDim.y, bz = blockIdx.y;
     const float fa = (MODE == DFX_SWEEP_XP) ? (float)scal[DFX_S_ALPHA] : 0.f;
     const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)scal[DFX_S_BETA] : 0.f;
     double dpp = 0, dxx = 0, dxp = 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (MODE == DFX_SWEEP_PROJECT) {
-            const float xv = x[i];
-            dxx += (double)(xv * xv);
-        } else if (MODE == DFX_SWEEP_XP) {
-            const float pv = p[i];
-            const float xn = x[i] + fa * pv;
-            const float pn = gen_resid(r, ra, rb, q, i) + fb * pv;
-            x[i] = xn;
-            p[i] = pn;
-            dxx += (double)(xn * xn);
-            dxp += (double)(xn * pn);
-            dpp += (double)(pn * pn);
-        } else if (MODE == DFX_SWEEP_P) {
-            const float pn = gen_resid(r, ra, rb, q, i) + fb * p[i];
-            p[i] = pn;
-            dpp += (double)(pn * pn);
-        } else {
-            const float xv = x[i], pn = gen_resid(r, ra, rb, q, i);
-            p[i] = pn;
-            dxx += (double)(xv * xv);
-            dxp += (double)(xv * pn);
-            dpp += (double)(pn * pn);
+    const int S = (int)q.S, P = (int)q.P;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int j[DFX_GEN_K], blk[DFX_GEN_K];
+        bool ok[DFX_GEN_K];
+        float rav[DFX_GEN_K], uf[DFX_GEN_K];
+        double ud[DFX_GEN_K];
+#pragma unroll
+        for (int k = 0; k < DFX_GEN_K; ++k) {
+            const long long jj = ((long long)tile * DFX_GEN_K + k) * 256 + threadIdx.x;
+            ok[k] = jj < S;
+            j[k] = ok[k] ? (int)jj : 0;
+            const int xy = j[k] % P, xi = xy / q.Y, yi = xy - xi * q.Y;
+            blk[k] = (xi / q.r) * q.Ys + yi / q.r;
+            rav[k] = (ra && ok[k]) ? ra[j[k]] : 0.f;
+            uf[k] = 0.f;
+            ud[k] = 0.0;
+        }
+        int run = 0;
+        for (int m = bz; m < q.M; m += gz) {
+            const long long base = (long long)m * S;
+            const float *rbm = rb ? rb + (long long)m * q.Ps : nullptr;
+            float xv[DFX_GEN_K], pv[DFX_GEN_K], rv[DFX_GEN_K];
+#pragma unroll
+            for (int k = 0; k < DFX_GEN_K; ++k) {
+                xv[k] = pv[k] = rv[k] = 0.f;
+                if (ok[k]) {
+                    const long long i = base + j[k];
+                    if (MODE != DFX_SWEEP_P) xv[k] = x[i];
+                    if (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) pv[k] = p[i];
+                    if (MODE != DFX_SWEEP_PROJECT) rv[k] = r ? r[i] : rav[k] + rbm[blk[k]];
+                }
+            }
+            float pp = 0.f, xx = 0.f, xp = 0.f;
+#pragma unroll
+            for (int k = 0; k < DFX_GEN_K; ++k) {
+                if (ok[k]) {
+                    const long long i = base + j[k];
+                    float pn;
+                    if (MODE == DFX_SWEEP_PROJECT) {
+                        pn = xv[k];
+                        xx += pn * pn;
+                    } else if (MODE == DFX_SWEEP_XP) {
+                        const float xn = xv[k] + fa * pv[k];
+                        pn = rv[k] + fb * pv[k];
+                        x[i] = xn;
+                        p[i] = pn;
+                        xx += xn * xn;
+                        xp += xn * pn;
+                        pp += pn * pn;
+                    } else if (MODE == DFX_SWEEP_P) {
+                        pn = rv[k] + fb * pv[k];
+                        p[i] = pn;
+                        pp += pn * pn;
+                    } else {
+                        pn = rv[k];
+                        p[i] = pn;
+                        xx += xv[k] * xv[k];
+                        xp += xv[k] * pn;
+                        pp += pn * pn;
+                    }
+                    uf[k] += pn;
+                }
+            }
+            dpp += (double)pp;
+            dxx += (double)xx;
+            dxp += (double)xp;
+            if (++run == 64) {   // bounds the length of an fp32 running sum, like the fast path's flush interval
+                run = 0;
+#pragma unroll
+                for (int k = 0; k < DFX_GEN_K; ++k) ud[k] += (double)uf[k], uf[k] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DFX_GEN_K; ++k)
+            if (ok[k]) u_part[(long long)bz * S + j[k]] = (float)(ud[k] + (double)uf[k]);
+    }
+    block_store3(dpp, dxx, dxp, part + ((long long)bz * gridDim.x + blockIdx.x) * DFX_NPART);
+}
+
+// The same with float4 lanes, for slabs whose length is a multiple of 4 (then every float4 of the FLAT volume is 16-byte
+// aligned whatever Y is): a thread owns DFX_GEN_K4 float4 groups of the slab, each wave-instruction moves 1 KiB of
+// contiguous memory and the accesses are non-temporal like the fast path's.  The four elements of a group may lie in
+// different rows and blocks (Y % 4 != 0), so each has its own block index for the rb gather.
+#ifndef DFX_GEN_K4
+#define DFX_GEN_K4 1      // measured at C2 size (126 x 126 planes, r = 3): 1: 3.20 ms, 2: 3.55, 4: 4.9
+#endif
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gen_sweep4(float *x, const float *r, const float *ra, const float *rb, float *p,
+                                                    const double *scal, Geo q, int n_tiles, float *u_part,
+                                                    double *part) {
+    const int gz = gridDim.y, bz = blockIdx.y;
+    const float fa = (MODE == DFX_SWEEP_XP) ? (float)scal[DFX_S_ALPHA] : 0.f;
+    const float fb = (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) ? (float)scal[DFX_S_BETA] : 0.f;
+    double dpp = 0, dxx = 0, dxp = 0;
+    const int S = (int)q.S, P = (int)q.P;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int j[DFX_GEN_K4], blk[DFX_GEN_K4][4];
+        bool ok[DFX_GEN_K4];
+        f4 rav[DFX_GEN_K4], uf[DFX_GEN_K4];
+#pragma unroll
+        for (int k = 0; k < DFX_GEN_K4; ++k) {
+            const long long jj = 4 * (((long long)tile * DFX_GEN_K4 + k) * 256 + threadIdx.x);
+            ok[k] = jj < S;
+            j[k] = ok[k] ? (int)jj : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int xy = (j[k] + e) % P, xi = xy / q.Y, yi = xy - xi * q.Y;
+                blk[k][e] = (xi / q.r) * q.Ys + yi / q.r;
+            }
+            rav[k] = (ra && ok[k]) ? ld4(ra + j[k]) : (f4){0.f, 0.f, 0.f, 0.f};
+            uf[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        }
+        int run = 0;
+        bool first = true;
+        for (int m = bz; m < q.M; m += gz) {
+            const long long base = (long long)m * S;
+            const float *rbm = rb ? rb + (long long)m * q.Ps : nullptr;
+            f4 xv[DFX_GEN_K4], pv[DFX_GEN_K4], rv[DFX_GEN_K4];
+#pragma unroll
+            for (int k = 0; k < DFX_GEN_K4; ++k) {
+                xv[k] = pv[k] = rv[k] = (f4){0.f, 0.f, 0.f, 0.f};
+                if (ok[k]) {
+                    const long long i = base + j[k];
+                    if (MODE != DFX_SWEEP_P) xv[k] = ld4s(x + i);
+                    if (MODE == DFX_SWEEP_XP || MODE == DFX_SWEEP_P) pv[k] = ld4s(p + i);
+                    if (MODE != DFX_SWEEP_PROJECT)
+                        rv[k] = r ? ld4s(r + i)
+                                  : rav[k] + (f4){rbm[blk[k][0]], rbm[blk[k][1]], rbm[blk[k][2]], rbm[blk[k][3]]};
+                }
+            }
+            float pp = 0.f, xx = 0.f, xp = 0.f;
+#pragma unroll
+            for (int k = 0; k < DFX_GEN_K4; ++k) {
+                if (ok[k]) {
+                    const long long i = base + j[k];
+                    f4 pn;
+                    if (MODE == DFX_SWEEP_PROJECT) {
+                        pn = xv[k];
+                        xx += dot4(pn, pn);
+                    } else if (MODE == DFX_SWEEP_XP) {
+                        const f4 xn = xv[k] + fa * pv[k];
+                        pn = rv[k] + fb * pv[k];
+                        st4s(x + i, xn);
+                        st4s(p + i, pn);
+                        xx += dot4(xn, xn);
+                        xp += dot4(xn, pn);
+                        pp += dot4(pn, pn);
+                    } else if (MODE == DFX_SWEEP_P) {
+                        pn = rv[k] + fb * pv[k];
+                        st4s(p + i, pn);
+                        pp += dot4(pn, pn);
+                    } else {
+                        pn = rv[k];
+                        st4s(p + i, pn);
+                        xx += dot4(xv[k], xv[k]);
+                        xp += dot4(xv[k], pn);
+                        pp += dot4(pn, pn);
+                    }
+                    uf[k] += pn;
+                }
+            }
+            dpp += (double)pp;
+            dxx += (double)xx;
+            dxp += (double)xp;
+            if (++run == 64) {   // flush: bounds the length of an fp32 running sum (the row is this workgroup row's own)
+                run = 0;
+#pragma unroll
+                for (int k = 0; k < DFX_GEN_K4; ++k) {
+                    if (ok[k]) {
+                        float *up = u_part + (long long)bz * S + j[k];
+                        st4(up, first ? uf[k] : uf[k] + ld4(up));
+                    }
+                    uf[k] = (f4){0.f, 0.f, 0.f, 0.f};
+                }
+                first = false;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DFX_GEN_K4; ++k) {
+            if (ok[k]) {
+                float *up = u_part + (long long)bz * S + j[k];
+                st4(up, first ? uf[k] : uf[k] + ld4(up));
+            }
         }
     }
-    block_store3(dpp, dxx, dxp, part + (long long)blockIdx.x * DFX_NPART);
+    block_store3(dpp, dxx, dxp, part + ((long long)bz * gridDim.x + blockIdx.x) * DFX_NPART);
 }
 
 __global__ __launch_bounds__(256) void k_gen_proj_u(const float *a, float *u, Geo q) {
@@ -977,6 +1149,63 @@ __global__ __launch_bounds__(256) void k_gen_proj_v(const float *a, float *v, Ge
                 for (int dy = 0; dy < q.r; ++dy) s += pl[(long long)(xb * q.r + dx) * q.Y + yb * q.r + dy];
         }
         v[j] = s;
+    }
+}
+
+// v of the generic path, second form: one wave per (slab, block row, column chunk); lanes walk the columns of the chunk
+// (coalesced row segments of up to 1 KiB) and add the nZ * r rows that feed the block row; the r columns of each block
+// are then added through a wave-private LDS row (LDS operations of one wave execute in order; wavefront-scope fences
+// for the compiler).  The first form gave every thread a whole block to gather (4 TB/s).
+__global__ __launch_bounds__(256) void k_gen_proj_v2(const float *a, float *v, Geo q) {
+    __shared__ float cs_all[4][256];
+    float *cs = cs_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int C = q.r * (256 / q.r);                       // chunk width: whole blocks, at most 256 columns
+    const int n_ch = (q.Y + C - 1) / C;
+    const long long items = (long long)q.M * q.Xs * n_ch;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    for (long long it = wid; it < items; it += nw) {
+        const int ch = (int)(it % n_ch);
+        const long long t = it / n_ch;
+        const int xb = (int)(t % q.Xs);
+        const long long m = t / q.Xs;
+        const int y0 = ch * C, cw = min(C, q.Y - y0);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float *row0 = a + m * q.S + (long long)(xb * q.r) * q.Y + y0;
+        const int n_rows = q.nZ * q.r;          // the rows that feed this block row, four at a time (loads in flight)
+        for (int rr0 = 0; rr0 < n_rows; rr0 += 4) {
+            float t[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = rr0 + u, z = rr / q.r, dx = rr - z * q.r;
+                const float *row = row0 + (long long)z * q.P + (long long)dx * q.Y;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = lane + 64 * k;
+                    t[u][k] = (rr < n_rows && c < cw) ? row[c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += t[u][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane + 64 * k;
+            if (c < cw) cs[c] = acc[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nb = cw / q.r;
+        for (int b = lane; b < nb; b += 64) {
+            float sum = 0.f;
+            for (int d = 0; d < q.r; ++d) sum += cs[b * q.r + d];
+            v[m * q.Ps + (long long)xb * q.Ys + y0 / q.r + b] = sum;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1618,6 +1847,35 @@ int ew_blocks(long long n, int per_thread) {
     return (int)b;
 }
 
+// workgroups along the slab positions of the generic sweep: one per tile of 256 * DFX_GEN_K positions, at most 2048
+// (a workgroup then walks several tiles)
+// k_gen_proj_v2: one wave per (slab, block row, column chunk) item, four waves per workgroup
+int gen_projv_blocks(const Geo &q) {
+    const int C = q.r <= 256 ? q.r * (256 / q.r) : q.r;
+    const long long items = (long long)q.M * q.Xs * ((q.Y + C - 1) / C);
+    long long b = (items + 3) / 4;
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;
+    return (int)b;
+}
+bool gen_vec4(const Geo &q) { return (q.S % 4) == 0; }   // float4 lanes over the flat volume (k_gen_sweep4)
+int gen_tiles(const Geo &q) {
+    const long long per = gen_vec4(q) ? 4LL * 256 * DFX_GEN_K4 : 256LL * DFX_GEN_K;
+    return (int)((q.S + per - 1) / per);
+}
+int gen_tile_slots(const Geo &q) {
+    const int t = gen_tiles(q);
+    return t < 2048 ? t : 2048;
+}
+
+// v of the generic path: the coalesced form for every block size a wave's LDS row can hold, the gather form beyond
+void launch_gen_proj_v(const float *src, float *v_part, const Geo &q, hipStream_t st) {
+    if (q.r <= 256)
+        hipLaunchKernelGGL(k_gen_proj_v2, dim3(gen_projv_blocks(q)), dim3(256), 0, st, src, v_part, q);
+    else
+        hipLaunchKernelGGL(k_gen_proj_v, dim3(ew_blocks((long long)q.M * q.Ps, 1)), dim3(256), 0, st, src, v_part, q);
+}
+
 int check_plan(const Geo &q, const dfx_plan *pl) {
     if (!pl) return fail(DFX_EPLAN, "plan is NULL");
     if (pl->steps <= 0 || pl->n_chunks <= 0 || pl->n_blocks <= 0 || pl->zc <= 0 || pl->n_zchunks <= 0)
@@ -1634,8 +1892,11 @@ int check_plan(const Geo &q, const dfx_plan *pl) {
         if (gz > 65535) return fail(DFX_EPLAN, "plan grid too large");
         const long long nb = (long long)((q.WT + DFX_WAVES - 1) / DFX_WAVES) * pl->n_zchunks * gz;
         if (nb != pl->n_blocks) return fail(DFX_EPLAN, "plan n_blocks inconsistent");
-    } else if (pl->n_chunks != 1 || pl->n_zchunks != 1) {
-        return fail(DFX_EPLAN, "generic plan must have n_chunks = n_zchunks = 1");
+    } else {
+        if (pl->n_zchunks != 1 || pl->cpb != 1) return fail(DFX_EPLAN, "generic plan must have n_zchunks = cpb = 1");
+        if (pl->n_chunks > q.M || pl->n_chunks > 4096 || (long long)pl->steps * pl->n_chunks < q.M)
+            return fail(DFX_EPLAN, "generic plan does not cover the geometry");
+        if ((long long)gen_tile_slots(q) * pl->n_chunks != pl->n_blocks) return fail(DFX_EPLAN, "plan n_blocks inconsistent");
     }
     return 0;
 }
@@ -1808,14 +2069,32 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         if (nb > 0x7fffffffLL) return fail(DFX_EINVAL, "too many workgroups");
         out->n_blocks = (int)nb;
     } else {
+        // generic kernels (k_gen_sweep2): grid = (tile slots, gz) with a tile = 256 * DFX_GEN_K slab positions; gz
+        // workgroups along the slab axis (one u_part row each) so that about two workgroups per CU are in flight
         out->fast = 0;
         out->zc = 1;
         out->zs = 1;
         out->n_zchunks = 1;
-        out->steps = q.M;
-        out->n_chunks = 1;
+        int dev = 0, cus = 0;
+        if (target_blocks <= 0) {
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+            (void)hipGetLastError();
+            // float4 lanes: two workgroups per CU; scalar lanes move a quarter of the bytes per instruction and want
+            // many more waves in flight (C2-sized volume, 125 x 125 planes: 8.1 ms at 2 per CU, 6.5 ms at 32)
+            target_blocks = (gen_vec4(q) ? 2 : 32) * cus;
+        }
+        const int slots = gen_tile_slots(q);
+        long long gz = (target_blocks + slots - 1) / slots;
+        if (gz > q.M) gz = q.M;
+        if (gz > 4096) gz = 4096;
+        if (gz < 1) gz = 1;
+        out->steps = (int)((q.M + gz - 1) / gz);
+        gz = (q.M + out->steps - 1) / out->steps;      // no workgroup row without a slab
+        out->n_chunks = (int)gz;
         out->cpb = 1;
-        out->n_blocks = ew_blocks(q.N, 4);
+        out->n_blocks = (int)(slots * gz);
     }
     out->u_part_elems = (long long)(out->n_chunks / out->cpb) * q.S;   // one row per workgroup of the slab axis
     out->v_part_elems = (long long)out->n_zchunks * q.M * q.Ps;
@@ -1868,25 +2147,25 @@ static int sweep_impl(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float
         n_rows = (slice + 1) * pl->n_blocks;
     } else {
         const int nb = pl->n_blocks;
+        const dim3 grid(gen_tile_slots(q), pl->n_chunks);
+        const int nt = gen_tiles(q);
+        const bool v4 = gen_vec4(q) && aligned16(x) && aligned16(p) && aligned16(r) && aligned16(ra) && aligned16(u_part);
+        if (gen_vec4(q) && !v4) return fail(DFX_EALIGN, "dfx_sweep: x, r, p, ra, u_part must be 16-byte aligned");
+#define DFX_GEN_LAUNCH(M_)                                                                                                 \
+    do {                                                                                                                  \
+        if (v4) hipLaunchKernelGGL(k_gen_sweep4<M_>, grid, dim3(256), 0, st, x, r, ra, rb, p, scal, q, nt, u_part, part);  \
+        else hipLaunchKernelGGL(k_gen_sweep2<M_>, grid, dim3(256), 0, st, x, r, ra, rb, p, scal, q, nt, u_part, part);    \
+    } while (0)
         switch (mode) {
-            case DFX_SWEEP_PROJECT:
-                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_PROJECT>, dim3(nb), dim3(256), 0, st, x, r, ra, rb, p, scal, q, part);
-                break;
-            case DFX_SWEEP_XP:
-                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_XP>, dim3(nb), dim3(256), 0, st, x, r, ra, rb, p, scal, q, part);
-                break;
-            case DFX_SWEEP_P:
-                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_P>, dim3(nb), dim3(256), 0, st, x, r, ra, rb, p, scal, q, part);
-                break;
-            default:
-                hipLaunchKernelGGL(k_gen_sweep<DFX_SWEEP_PINIT>, dim3(nb), dim3(256), 0, st, x, r, ra, rb, p, scal, q, part);
-                break;
+            case DFX_SWEEP_PROJECT: DFX_GEN_LAUNCH(DFX_SWEEP_PROJECT); break;
+            case DFX_SWEEP_XP: DFX_GEN_LAUNCH(DFX_SWEEP_XP); break;
+            case DFX_SWEEP_P: DFX_GEN_LAUNCH(DFX_SWEEP_P); break;
+            default: DFX_GEN_LAUNCH(DFX_SWEEP_PINIT); break;
         }
+#undef DFX_GEN_LAUNCH
         DFX_LAUNCH_CHECK("dfx_sweep(generic)");
         const float *src = (mode == DFX_SWEEP_PROJECT) ? x : p;
-        hipLaunchKernelGGL(k_gen_proj_u, dim3(ew_blocks(q.S, 1)), dim3(256), 0, st, src, u_part, q);
-        DFX_LAUNCH_CHECK("dfx_sweep(generic u)");
-        hipLaunchKernelGGL(k_gen_proj_v, dim3(ew_blocks((long long)q.M * q.Ps, 1)), dim3(256), 0, st, src, v_part, q);
+        launch_gen_proj_v(src, v_part, q, st);
         DFX_LAUNCH_CHECK("dfx_sweep(generic v)");
         n_rows = nb;
     }
@@ -2052,8 +2331,11 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
         DFX_LAUNCH_CHECK("dfx_adam_step(generic)");
         hipLaunchKernelGGL(k_gen_proj_u, dim3(ew_blocks(q.S, 1)), dim3(256), 0, st, (const float *)x, u_part, q);
         DFX_LAUNCH_CHECK("dfx_adam_step(generic u)");
-        hipLaunchKernelGGL(k_gen_proj_v, dim3(ew_blocks((long long)q.M * q.Ps, 1)), dim3(256), 0, st, (const float *)x,
-                           v_part, q);
+        if (pl->n_chunks > 1) {   // the generic plan has one u_part row per slab-axis workgroup of the sweep; this pass fills row 0
+            hipError_t e = hipMemsetAsync(u_part + q.S, 0, sizeof(float) * (size_t)(pl->n_chunks - 1) * (size_t)q.S, st);
+            if (e != hipSuccess) return hipfail(e, "dfx_adam_step(generic u rows)");
+        }
+        launch_gen_proj_v((const float *)x, v_part, q, st);
         DFX_LAUNCH_CHECK("dfx_adam_step(generic v)");
     }
     // the rows are left for dfx_post_sweep(DFX_POST_FOLD_ADAM), or this is not the final slice

@@ -39,7 +39,7 @@ typedef struct dfx_geom {
 } dfx_geom;
 
 /* Launch plan + workspace sizes for one geometry.  fast=1: float4 wave-tile kernels
- * (Y % 4 == 0 and r in {2, 4, 8} - or, through a general tile, {3, 5, 6, 7, 10, 12, 16}; small-space rows B / v_part
+ * (Y % 4 == 0 and r in {2, 4, 8} - or, through a general tile, {3, 5, 7, 16}; small-space rows B / v_part
  * 8-byte aligned when r = 2); fast=0: shape-generic kernels (any r, any Y). */
 typedef struct dfx_plan {
     int32_t fast;

@@ -27,7 +27,8 @@ int main() {
                 pl.n_chunks % pl.cpb || pl.u_part_elems != (long long)(pl.n_chunks / pl.cpb) * S ||
                 pl.v_part_elems != (long long)pl.n_zchunks * M * Ps)
                 { std::printf("inconsistent fast plan\n"); ++bad; }
-        } else if (pl.n_chunks != 1 || pl.n_zchunks != 1) { std::printf("inconsistent generic plan\n"); ++bad; }
+        } else if (pl.n_zchunks != 1 || pl.cpb != 1 || pl.n_chunks < 1 || pl.n_chunks > M || (long long)pl.steps * pl.n_chunks < M ||
+                   pl.n_blocks % pl.n_chunks || pl.u_part_elems != (long long)pl.n_chunks * S) { std::printf("inconsistent generic plan\n"); ++bad; }
         if (pl.part_elems < (long long)(pl.n_blocks * DFX_MAX_SLICES + DFX_EW_MAXBLOCKS) * DFX_NPART) { std::printf("part too small\n"); ++bad; }
         // every entry point must reject NULL buffers / bad ranges before touching the device
         float *nf = nullptr; double *nd = nullptr;

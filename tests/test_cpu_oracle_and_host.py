@@ -163,7 +163,7 @@ def test_planner_covers_geometry(dims, fast):
         assert 0 < p.zs <= p.zc and p.zs * p.n_zchunks >= n_z and p.steps * p.n_chunks >= n_t * n_l
         assert (p.n_zchunks - 1) * p.zs < n_z and p.n_zchunks * p.zs - n_z < p.n_zchunks      # balanced chunks
     else:
-        assert p.n_chunks == 1 and p.n_zchunks == 1
+        assert p.n_zchunks == 1 and p.cpb == 1 and 1 <= p.n_chunks <= n_t * n_l and p.n_blocks % p.n_chunks == 0
     assert p.u_part_elems == (p.n_chunks // max(p.cpb, 1)) * n_z * X * Y
     assert p.v_part_elems == p.n_zchunks * n_t * n_l * (X // r) * (Y // r)
     assert p.part_elems >= max(p.n_blocks, cabi.EW_MAXBLOCKS) * cabi.NPART

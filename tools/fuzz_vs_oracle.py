@@ -24,7 +24,7 @@ def main():
     rng = random.Random(a.seed)
     worst = 0.0
     for case in range(a.cases):
-        r = rng.choice([2, 4, 4, 4, 8, 3, 3, 5, 6, 7, 9, 10, 12, 16])     # 3, 5, 6, 7, 10, 12, 16: LaneMap<0> when Y % 4 == 0
+        r = rng.choice([2, 4, 4, 4, 8, 3, 3, 5, 6, 7, 9, 10, 12, 16])     # 3, 5, 7, 16: LaneMap<0> when Y % 4 == 0
         xs = rng.randint(1, max(2, 96 // r))
         if r not in (2, 4, 8) and rng.random() < 0.6:
             xs = 4 * ((xs + 3) // 4)                                       # Y = xs r a multiple of 4: the general-r fast path
