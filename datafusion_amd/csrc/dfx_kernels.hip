@@ -1228,6 +1228,94 @@ __global__ __launch_bounds__(256) void k_gen_bcast(BcastArgs a) {
     block_store3(drr, 0.0, 0.0, a.part + (long long)blockIdx.x * DFX_NPART);
 }
 
+// The generic broadcast-axpy and fused Adam step with float4 lanes over the flat volume (slab length a multiple of 4),
+// in the structure of k_gen_sweep4: thread-owned slab positions, everything that depends on the position only (A, mask,
+// the blocks under the four elements, m1a) worked out once, the slabs walked with 1 KiB per wave-instruction.  The
+// element-wise forms above (index arithmetic per element) stay for slabs whose length is not a multiple of 4.
+__global__ __launch_bounds__(256) void k_gen_bcast4(BcastArgs a, int n_tiles) {
+    const int gz = gridDim.y, bz = blockIdx.y;
+    const float coef = a.coef_host * (a.coef_dev ? (float)(*a.coef_dev) : 1.f);
+    const float ca = coef * a.sa, cb = coef * a.sb;
+    const int S = (int)a.q.S, P = (int)a.q.P;
+    double drr = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long jj = 4 * ((long long)tile * 256 + threadIdx.x);
+        if (jj >= S) continue;
+        const int j = (int)jj;
+        int blk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int xy = (j + e) % P, xi = xy / a.q.Y, yi = xy - xi * a.q.Y;
+            blk[e] = (xi / a.q.r) * a.q.Ys + yi / a.q.r;
+        }
+        const f4 av = ca * ld4(a.A + j);
+        const f4 mk = a.mask ? ld4(a.mask + j) : (f4){1.f, 1.f, 1.f, 1.f};
+        for (int m = bz; m < a.q.M; m += gz) {
+            const long long i = (long long)m * S + j;
+            const float *bm = a.B + (long long)m * a.q.Ps;
+            f4 o = (av + cb * (f4){bm[blk[0]], bm[blk[1]], bm[blk[2]], bm[blk[3]]}) * mk;
+            if (a.in) o += ld4s(a.in + i);
+            st4s(a.out + i, o);
+            drr += (double)dot4(o, o);
+        }
+    }
+    block_store3(drr, 0.0, 0.0, a.part + ((long long)bz * gridDim.x + blockIdx.x) * DFX_NPART);
+}
+
+template <bool M1F>
+__global__ __launch_bounds__(256) void k_gen_adam4(AdamArgs a, int n_tiles) {
+    const int gz = gridDim.y, bz = blockIdx.y;
+    const int S = (int)a.q.S, P = (int)a.q.P;
+    double ddd = 0, dxx = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long jj = 4 * ((long long)tile * 256 + threadIdx.x);
+        if (jj >= S) continue;
+        const int j = (int)jj;
+        int blk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int xy = (j + e) % P, xi = xy / a.q.Y, yi = xy - xi * a.q.Y;
+            blk[e] = (xi / a.q.r) * a.q.Ys + yi / a.q.r;
+        }
+        const f4 av = ld4(a.A + j);
+        const f4 mk = a.mask ? ld4(a.mask + j) : (f4){1.f, 1.f, 1.f, 1.f};
+        const f4 m1av = M1F ? ld4(a.m1a + j) : (f4){0.f, 0.f, 0.f, 0.f};
+        f4 uf = {0.f, 0.f, 0.f, 0.f};
+        float *up = a.u_part + (long long)bz * S + j;
+        int run = 0;
+        bool first = true;
+        for (int m = bz; m < a.q.M; m += gz) {
+            const long long i = (long long)m * S + j;
+            const float *bm = a.B + (long long)m * a.q.Ps;
+            const f4 xo = ld4s(a.x + i);
+            f4 e2 = ld4s(a.m2 + i), e1;
+            if (M1F) {
+                const float *mbm = a.m1b + (long long)m * a.q.Ps;
+                e1 = (m1av + (f4){mbm[blk[0]], mbm[blk[1]], mbm[blk[2]], mbm[blk[3]]}) * mk;
+            } else {
+                e1 = ld4s(a.m1 + i);
+            }
+            const f4 gr = (av + (f4){bm[blk[0]], bm[blk[1]], bm[blk[2]], bm[blk[3]]}) * mk;
+            const f4 xn = adam_elem4<M1F, false>(xo, gr, e1, e2, a);      // the generic kernels' arithmetic: IEEE
+            st4s(a.x + i, xn);
+            if (!M1F) st4s(a.m1 + i, e1);
+            st4s(a.m2 + i, e2);
+            const f4 d = xn - xo;
+            ddd += (double)dot4(d, d);
+            dxx += (double)dot4(xn, xn);
+            uf += xn;
+            if (++run == 64) {
+                run = 0;
+                st4(up, first ? uf : uf + ld4(up));
+                uf = (f4){0.f, 0.f, 0.f, 0.f};
+                first = false;
+            }
+        }
+        st4(up, first ? uf : uf + ld4(up));
+    }
+    block_store3(ddd, dxx, 0.0, a.part + ((long long)bz * gridDim.x + blockIdx.x) * DFX_NPART);
+}
+
 // ------------------------------------------------------------------------------------------
 // Small-space reductions and scalar bookkeeping
 // ------------------------------------------------------------------------------------------
@@ -2273,7 +2361,10 @@ int dfx_bcast(const dfx_geom *g, const dfx_plan *pl, float *out, const float *in
         n_rows = pl->n_blocks;
     } else {
         n_rows = pl->n_blocks;
-        hipLaunchKernelGGL(k_gen_bcast, dim3(n_rows), dim3(256), 0, st, a);
+        if (gen_vec4(q) && aligned16(out) && aligned16(in) && aligned16(A) && aligned16(mask))
+            hipLaunchKernelGGL(k_gen_bcast4, dim3(gen_tile_slots(q), pl->n_chunks), dim3(256), 0, st, a, gen_tiles(q));
+        else
+            hipLaunchKernelGGL(k_gen_bcast, dim3(n_rows), dim3(256), 0, st, a);
         DFX_LAUNCH_CHECK("dfx_bcast(generic)");
     }
     return fold(part, n_rows, 1, scal + DFX_S_RR, 1.0, st);
@@ -2327,13 +2418,21 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
         n_rows = (slice + 1) * pl->n_blocks;
     } else {
         n_rows = pl->n_blocks;
-        hipLaunchKernelGGL(k_gen_adam, dim3(n_rows), dim3(256), 0, st, a);
-        DFX_LAUNCH_CHECK("dfx_adam_step(generic)");
-        hipLaunchKernelGGL(k_gen_proj_u, dim3(ew_blocks(q.S, 1)), dim3(256), 0, st, (const float *)x, u_part, q);
-        DFX_LAUNCH_CHECK("dfx_adam_step(generic u)");
-        if (pl->n_chunks > 1) {   // the generic plan has one u_part row per slab-axis workgroup of the sweep; this pass fills row 0
-            hipError_t e = hipMemsetAsync(u_part + q.S, 0, sizeof(float) * (size_t)(pl->n_chunks - 1) * (size_t)q.S, st);
-            if (e != hipSuccess) return hipfail(e, "dfx_adam_step(generic u rows)");
+        if (gen_vec4(q) && aligned16(x) && aligned16(m1) && aligned16(m2) && aligned16(A) && aligned16(mask) &&
+            aligned16(m1a) && aligned16(u_part)) {
+            const dim3 grid(gen_tile_slots(q), pl->n_chunks);
+            if (m1f) hipLaunchKernelGGL(k_gen_adam4<true>, grid, dim3(256), 0, st, a, gen_tiles(q));
+            else hipLaunchKernelGGL(k_gen_adam4<false>, grid, dim3(256), 0, st, a, gen_tiles(q));
+            DFX_LAUNCH_CHECK("dfx_adam_step(generic)");
+        } else {
+            hipLaunchKernelGGL(k_gen_adam, dim3(n_rows), dim3(256), 0, st, a);
+            DFX_LAUNCH_CHECK("dfx_adam_step(generic)");
+            hipLaunchKernelGGL(k_gen_proj_u, dim3(ew_blocks(q.S, 1)), dim3(256), 0, st, (const float *)x, u_part, q);
+            DFX_LAUNCH_CHECK("dfx_adam_step(generic u)");
+            if (pl->n_chunks > 1) {   // the generic plan has one u_part row per slab-axis workgroup of the sweep; this pass fills row 0
+                hipError_t e = hipMemsetAsync(u_part + q.S, 0, sizeof(float) * (size_t)(pl->n_chunks - 1) * (size_t)q.S, st);
+                if (e != hipSuccess) return hipfail(e, "dfx_adam_step(generic u rows)");
+            }
         }
         launch_gen_proj_v((const float *)x, v_part, q, st);
         DFX_LAUNCH_CHECK("dfx_adam_step(generic v)");
