@@ -48,6 +48,9 @@ WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "c2r16": (256, 16, 16, 128, 16),
     "c2gen": (256, 16, 16, 126, 3),      # Y % 4 != 0: the generic kernels (flat float4 sweep + the v pass)
     "c2odd": (256, 16, 15, 125, 5),      # slab length not a multiple of 4: the generic kernels with scalar lanes
+    "p512s": (16, 4, 16, 512, 4),        # wide planes (more workgroups than CUs) with few / many slabs per workgroup
+    "p512m": (64, 16, 16, 512, 4),
+    "p1k": (4, 2, 8, 1024, 4),
     "tiny": (8, 4, 4, 64, 4),
 }
 

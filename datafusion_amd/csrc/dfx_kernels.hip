@@ -1992,6 +1992,46 @@ int check_plan(const Geo &q, const dfx_plan *pl) {
 bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 bool aligned8(const void *p) { return (((uintptr_t)p) & 7) == 0; }   // small-space rows: float2 access when r = 2
 
+// One workgroup per CU for the lane-mapped streaming kernels.  They stream fastest at ONE 4-wave workgroup per CU (see
+// dfx_plan_make_ex); a plane of 512 x 512 and more has more (tile group, z-chunk) pairs than the chip has CUs, and the
+// dispatcher would then run up to four workgroups per CU side by side (four concurrent windows per vector).  A dynamic
+// LDS request of more than half a CU's 160 KiB (never touched by the kernels) makes the hardware admit one workgroup
+// per CU, the rest following as CUs drain: config 4 whole on one GPU 90.1 -> 88.4 ms, t64 x l16 x z16 x 512^2
+// 11.29 -> 10.94 ms, t16 x l4 x z16 x 512^2 0.793 -> 0.731 ms; launches of at most one workgroup per CU are unchanged.
+// DFX_SOLO_LDS=<bytes> overrides (0: off).
+static int solo_lds_bytes() {
+    static const int v = [] {
+        const char *e = getenv("DFX_SOLO_LDS");
+        int want = e ? atoi(e) : 96 * 1024;
+        if (want < 0) want = 0;
+        return want;
+    }();
+    return v;
+}
+#define DFX_LAUNCH_SOLO(KFN, grid, block, st, ...)                                                                   \
+    do {                                                                                                             \
+        auto kfn_ = KFN;                                                                                             \
+        static unsigned long long ok_ = 0, bad_ = 0;   /* per kernel instance: devices (bit = id) with the attribute set */ \
+        int dyn_ = solo_lds_bytes();                                                                                 \
+        if (dyn_ > 0) {                                                                                              \
+            int dev_ = 0;                                                                                            \
+            (void)hipGetDevice(&dev_);                                                                               \
+            const unsigned long long bit_ = 1ull << (dev_ & 63);                                                     \
+            if (!((ok_ | bad_) & bit_)) {                                                                            \
+                int cap_ = 0;                                                                                        \
+                if (hipDeviceGetAttribute(&cap_, hipDeviceAttributeMaxSharedMemoryPerBlock, dev_) == hipSuccess &&   \
+                    cap_ >= dyn_ + 16 * 1024 &&                                                                      \
+                    hipFuncSetAttribute((const void *)kfn_, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_) ==     \
+                        hipSuccess)                                                                                  \
+                    ok_ |= bit_;                                                                                     \
+                else                                                                                                 \
+                    bad_ |= bit_, (void)hipGetLastError();                                                           \
+            }                                                                                                        \
+            if (bad_ & bit_) dyn_ = 0;                                                                               \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kfn_, grid, block, dyn_, st, __VA_ARGS__);                                                \
+    } while (0)
+
 // the fast kernels exist for zc in {4, 8} x r in {2, 4, 8, general (LaneMap<0>)}; check_plan / fast_ok admit nothing else
 #define DFX_DISPATCH_R(ZCV, r, ...)                                        \
     do {                                                                   \
@@ -2011,9 +2051,9 @@ template <int MODE>
 int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
     dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
     if (MODE != DFX_SWEEP_PROJECT && a.ra)
-        DFX_DISPATCH_ZC_R(pl->zc, a.q.r, hipLaunchKernelGGL((k_sweep_fast<MODE, ZC_, R_, MODE != DFX_SWEEP_PROJECT>), grid, block, 0, st, a));
+        DFX_DISPATCH_ZC_R(pl->zc, a.q.r, DFX_LAUNCH_SOLO((k_sweep_fast<MODE, ZC_, R_, MODE != DFX_SWEEP_PROJECT>), grid, block, st, a));
     else
-        DFX_DISPATCH_ZC_R(pl->zc, a.q.r, hipLaunchKernelGGL((k_sweep_fast<MODE, ZC_, R_, false>), grid, block, 0, st, a));
+        DFX_DISPATCH_ZC_R(pl->zc, a.q.r, DFX_LAUNCH_SOLO((k_sweep_fast<MODE, ZC_, R_, false>), grid, block, st, a));
     DFX_LAUNCH_CHECK("dfx_sweep(fast)");
     return 0;
 }
@@ -2021,7 +2061,7 @@ int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
 template <bool HAS_IN, bool HAS_MASK>
 int launch_bcast_fast(const BcastArgs &a, const dfx_plan *pl, hipStream_t st) {
     dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
-    DFX_DISPATCH_ZC_R(pl->zc, a.q.r, hipLaunchKernelGGL((k_bcast_fast<ZC_, R_, HAS_IN, HAS_MASK>), grid, block, 0, st, a));
+    DFX_DISPATCH_ZC_R(pl->zc, a.q.r, DFX_LAUNCH_SOLO((k_bcast_fast<ZC_, R_, HAS_IN, HAS_MASK>), grid, block, st, a));
     DFX_LAUNCH_CHECK("dfx_bcast(fast)");
     return 0;
 }
@@ -2407,13 +2447,13 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
         dim3 grid((q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb),
             block(64 * DFX_WAVES);
         if (mask && m1f)
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, true, true>), grid, block, 0, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, true, true>), grid, block, st, a));
         else if (mask)
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, true, false>), grid, block, 0, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, true, false>), grid, block, st, a));
         else if (m1f)
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false, true>), grid, block, 0, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, true>), grid, block, st, a));
         else
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false, false>), grid, block, 0, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, false>), grid, block, st, a));
         DFX_LAUNCH_CHECK("dfx_adam_step(fast)");
         n_rows = (slice + 1) * pl->n_blocks;
     } else {
@@ -2522,7 +2562,7 @@ int dfx_adam_apply_project(const dfx_geom *g, const dfx_plan *pl, float *x, cons
                (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
                (flags & DFX_ADAM_NONNEG) ? 1 : 0, q, pl->steps, pl->cpb, 0, pl->cpb, 0, grad};
     dim3 grid((q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
-    DFX_DISPATCH_ZC_R(pl->zc, q.r, hipLaunchKernelGGL((k_adam_fast<ZC_, R_, false, false, true>), grid, block, 0, st, a));
+    DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, false, true>), grid, block, st, a));
     DFX_LAUNCH_CHECK("dfx_adam_apply_project");
     return 0;   // u, v, ADAM_DD, ADAM_XX, TOL: dfx_post_sweep(DFX_POST_U | DFX_POST_V | DFX_POST_FOLD_ADAM)
 }
