@@ -39,13 +39,14 @@ WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "cells": (64, 16, 20, 128, 4),       # README-like
     "c2r2": (256, 16, 16, 128, 2),       # C2 volume with spatial_increase 2 / 8 (LaneMap<2>, LaneMap<8>)
     "c2r8": (256, 16, 16, 128, 8),
-    "c2r3": (256, 16, 16, 120, 3),       # other block sizes: general tile (LaneMap<0>: r = 3, 5, 7, 16 with Y % 4 == 0), else the generic kernels
+    "c2r3": (256, 16, 16, 120, 3),       # other block sizes: general tile (LaneMap<0>: r = 3, 5, 7 with Y % 4 == 0), else the generic kernels
     "c2r5": (256, 16, 16, 120, 5),
     "c2r6": (256, 16, 16, 120, 6),
     "c2r7": (256, 16, 16, 112, 7),
     "c2r10": (256, 16, 16, 120, 10),
     "c2r12": (256, 16, 16, 120, 12),
-    "c2r16": (256, 16, 16, 128, 16),
+    "c2r16": (256, 16, 16, 128, 16),     # row-part tile (LaneMap<16>: r = 16, 32, 64)
+    "c2r32": (256, 16, 16, 128, 32),
     "c2gen": (256, 16, 16, 126, 3),      # Y % 4 != 0: the generic kernels (flat float4 sweep + the v pass)
     "c2odd": (256, 16, 15, 125, 5),      # slab length not a multiple of 4: the generic kernels with scalar lanes
     "p512s": (16, 4, 16, 512, 4),        # wide planes (more workgroups than CUs) with few / many slabs per workgroup

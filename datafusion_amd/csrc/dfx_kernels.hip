@@ -80,7 +80,9 @@ struct Geo {
     int WT;        // wave tiles per plane (fast path): ceil(nblk / BW), BW = 64, 16, 4 blocks per wave for r = 2, 4, 8;
                    // general r (LaneMap<0>): Xs * gTPR
     int gL;        // general r: lanes (float4) per tile row, 0 when r has no such tile; tile = r rows x 4 gL columns
-    int gTPR;      // general r: tiles per band of r rows = ceil(Y / (4 gL))
+    int gTPR;      // general r: tiles per band of r rows = ceil(Y / (4 gL)); row-part tile: column groups ceil(Y / 64)
+    int vq;        // row-part tile (LaneMap<16>: r = 16, 32, 64): r / 4 waves share a block, each writes its own layer of
+                   // v_part; 1 for every other map.  v_part holds n_zchunks * vq layers of M * Ps floats.
     int nblk;      // r x r blocks per plane = Xs*Ys
     int zs;        // planes per z-chunk of the plan in use (<= the kernel's ZC); set by the entry points
 };
@@ -98,6 +100,13 @@ int general_lanes_per_row(int r) {
     if (!(r == 3 || r == 5 || r == 7 || r == 16)) return 0;
     const int g = (r % 4 == 0) ? 4 : (r % 2 == 0 ? 2 : 1), q = r / g;
     return (64 / r) / q * q;
+}
+
+// Row-part tile (LaneMap<16>): r = 16, 32, 64 with the wave shape of r = 4 (4 rows x 64 columns, 256 B row segments);
+// a block's r rows are spread over r / 4 waves, which leave their partial block sums in layers of v_part.
+bool rowpart_tile(int r) {
+    static const bool off = getenv("DFX_NO_ROWPART_TILE") != nullptr;   // measurement knob: 16 -> general tile, 32 / 64 -> generic
+    return !off && (r == 16 || r == 32 || r == 64);
 }
 
 int make_geo(const dfx_geom *g, Geo *o) {
@@ -122,9 +131,16 @@ int make_geo(const dfx_geom *g, Geo *o) {
     if (o->S > 0x7fffffffLL) return fail(DFX_EINVAL, "one (t,l) slab must stay below 2^31 elements");
     o->nblk = o->Xs * o->Ys;
     o->gL = o->gTPR = 0;
+    o->vq = 1;
     if (o->r == 2 || o->r == 4 || o->r == 8) {
         const int bw = o->r == 2 ? 64 : (o->r == 8 ? 4 : 16);   // LaneMap<R>::BW
         o->WT = (o->nblk + bw - 1) / bw;
+    } else if (rowpart_tile(o->r)) {
+        o->vq = o->r / 4;
+        o->gTPR = (o->Y + 63) / 64;
+        const long long wt = (long long)o->Xs * o->gTPR * o->vq;
+        if (wt > 0x7fffffffLL) return fail(DFX_EINVAL, "plane too large");
+        o->WT = (int)wt;
     } else {
         o->gL = general_lanes_per_row(o->r);
         o->gTPR = o->gL ? (o->Y + 4 * o->gL - 1) / (4 * o->gL) : 0;
@@ -135,7 +151,7 @@ int make_geo(const dfx_geom *g, Geo *o) {
 
 // Y a multiple of 4 (every plane row 16-byte aligned) and r in {2, 4, 8} - a float4 never straddles a block row
 // (r = 4, 8) or covers exactly two blocks (r = 2), LaneMap<R> - or an r with a general tile (LaneMap<0>: 3, 5, 7, 16).
-bool fast_ok(const Geo &q) { return (q.r == 2 || q.r == 4 || q.r == 8 || q.gL > 0) && (q.Y % 4) == 0; }
+bool fast_ok(const Geo &q) { return (q.r == 2 || q.r == 4 || q.r == 8 || q.gL > 0 || q.vq > 1) && (q.Y % 4) == 0; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -362,6 +378,53 @@ struct LaneMap<0> {
     }
 };
 
+// Row-part tile (R = 16: r = 16, 32, 64).  The wave has the shape of r = 4 - 4 rows x 16 float4, 256 B per row segment -
+// and covers a quarter-block-high strip of 64 / r blocks; the r / 4 strips of a band of r rows belong to consecutive
+// wave tiles (the waves of one workgroup for r = 16).  A wave adds its 4 rows x r columns per block with shuffles and
+// stores the partial in ITS layer of v_part (layer = z-chunk * r/4 + row part); the layers are added where the
+// z-chunks' are (dfx_post_sweep / dfx_reduce_v).  The general tile's 16 x 16 wave (64 B row segments, cached accesses)
+// ran the C2 volume with r = 16 at 0.68 of peak.
+template <>
+struct LaneMap<16> {
+    int blk;
+    bool act, lead;
+    long long off2;
+    int part;         // which 4 rows of the block's r
+    int r;
+    __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
+        r = q.r;
+        part = wt % q.vq;
+        const int t = wt / q.vq;
+        const int xb = t / q.gTPR, cg = t - xb * q.gTPR;
+        const int dx = lane >> 4, j = lane & 15;
+        const int col = cg * 64 + 4 * j;
+        act = wt < q.WT && col < q.Y;
+        off2 = (long long)(xb * r + part * 4 + dx) * q.Y + col;
+        blk = xb * q.Ys + col / r;
+        lead = act && dx == 0 && (col % r) == 0;
+    }
+    __device__ __forceinline__ void vstore(f4 s4, float *vrow, int lane) const {
+        float s = hsum(s4);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (r >= 32) s += __shfl_xor(s, 4);
+        if (r >= 64) s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lead) vrow[blk] = s;
+    }
+    __device__ __forceinline__ f4 bload(const float *brow) const {
+        const float b = brow[blk];
+        return (f4){b, b, b, b};
+    }
+};
+// the layer of v_part a wave writes: its z-chunk, times the row parts of the row-part tile
+template <int R>
+__device__ __forceinline__ long long v_layer(const LaneMap<R> &L, const Geo &q) {
+    if constexpr (R == 16) return (long long)blockIdx.y * q.vq + L.part;
+    else return (long long)blockIdx.y;
+}
+
 // ------------------------------------------------------------------------------------------
 // Fast sweep: x += alpha p ; p = r + beta p ; u(p), v(p), ||p||^2, ||x||^2, <x,p>   (MODE XP)
 // ------------------------------------------------------------------------------------------
@@ -389,7 +452,7 @@ template <int MODE, int ZC, int R, bool FACT, int ZN>
 __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, int ms, long long off,
                                             const LaneMap<R> &L, float fa, float fb, const f4 (&rav)[ZC],
                                             f4 (&uacc)[ZC], double &dpp, double &dxx, double &dxp) {
-    float *vbase = a.v_part + (long long)blockIdx.y * a.q.M * a.q.Ps;
+    float *vbase = a.v_part + v_layer(L, a.q) * a.q.M * a.q.Ps;
     const int lane = threadIdx.x & 63;
     // the ZN live planes go in groups of DFX_ZB (loads issued together, then updated and stored); the LAST group takes
     // the remainder too (ZN = 5 -> 2 + 3, 7 -> 2 + 2 + 3), so that no group runs with fewer loads in flight than the
@@ -782,7 +845,7 @@ __global__ __launch_bounds__(64 * DFX_WAVES, DFX_MINWAVES) void k_adam_fast(cons
     const LaneMap<R> L(a.q, wt, lane);
     if (L.act) {
         const long long off = (long long)z0 * a.q.P + L.off2;
-        float *vbase = a.v_part + (long long)blockIdx.y * a.q.M * a.q.Ps;
+        float *vbase = a.v_part + v_layer(L, a.q) * a.q.M * a.q.Ps;
         f4 av[ZC], mk[ZC], m1av[ZC];
 #pragma unroll
         for (int k = 0; k < ZC; ++k) {
@@ -1609,6 +1672,38 @@ __global__ __launch_bounds__(256) void k_resid_az(float *ra, const float *A, dou
     block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
 }
 
+// The same for large blocks (r >= 16: r^2 >= 256 elements per block and plane): a WORKGROUP per block, its threads
+// over the block's nZ * r * r elements (row segments of r contiguous floats).  Thread-per-block above walks r^2 elements
+// per plane serially and leaves one workgroup per 16 blocks: 0.58 ms at t256 x l16 x z16 x 128^2 with r = 32 (16 blocks).
+__global__ __launch_bounds__(256) void k_resid_az_wide(float *ra, const float *A, double *zab, Geo q, float sa,
+                                                       float coef_host, const double *coef_dev, int accumulate,
+                                                       double *part) {
+    __shared__ double shw[4];
+    const float c = coef_host * (coef_dev ? (float)(*coef_dev) : 1.f) * sa;
+    const int r = q.r, rr = r * r;
+    const int per = q.nZ * rr;   // <= S < 2^31
+    double acc = 0;
+    for (int j = blockIdx.x; j < (int)q.Ps; j += gridDim.x) {
+        const int xb = j / q.Ys, yb = j - xb * q.Ys;
+        const long long o0 = (long long)(xb * r) * q.Y + yb * r;
+        double bs = 0;
+        for (int e = threadIdx.x; e < per; e += 256) {
+            const int z = e / rr, w = e - z * rr, dx = w / r, dy = w - dx * r;
+            const long long i = (long long)z * q.P + o0 + (long long)dx * q.Y + dy;
+            const float v = (accumulate ? ra[i] : 0.f) + c * A[i];
+            ra[i] = v;
+            acc += (double)v * (double)v;
+            bs += (double)v;
+        }
+        bs = wave_sum(bs);
+        if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = bs;
+        __syncthreads();
+        if (threadIdx.x == 0) zab[j] = (shw[0] + shw[1]) + (shw[2] + shw[3]);
+        __syncthreads();
+    }
+    block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
+}
+
 // rb update + sum rb^2 + sum rb*zab: a workgroup takes whole rows (t,l) of rb, so the zab index needs no modulo
 __global__ __launch_bounds__(256) void k_resid_b(float *rb, const float *B, const double *zab, int M, int Ps,
                                                  float sb, float coef_host, const double *coef_dev, int accumulate,
@@ -2032,13 +2127,14 @@ static int solo_lds_bytes() {
         hipLaunchKernelGGL(kfn_, grid, block, dyn_, st, __VA_ARGS__);                                                \
     } while (0)
 
-// the fast kernels exist for zc in {4, 8} x r in {2, 4, 8, general (LaneMap<0>)}; check_plan / fast_ok admit nothing else
+// the fast kernels exist for zc in {4, 8} x r in {2, 4, 8, row-part tile (LaneMap<16>), general (LaneMap<0>)}; check_plan / fast_ok admit nothing else
 #define DFX_DISPATCH_R(ZCV, r, ...)                                        \
     do {                                                                   \
         constexpr int ZC_ = ZCV;                                           \
         if ((r) == 2) { constexpr int R_ = 2; __VA_ARGS__; }               \
         else if ((r) == 4) { constexpr int R_ = 4; __VA_ARGS__; }          \
         else if ((r) == 8) { constexpr int R_ = 8; __VA_ARGS__; }          \
+        else if (rowpart_tile(r)) { constexpr int R_ = 16; __VA_ARGS__; }  \
         else { constexpr int R_ = 0; __VA_ARGS__; }                        \
     } while (0)
 #define DFX_DISPATCH_ZC_R(zc, r, ...)                                      \
@@ -2225,7 +2321,7 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         out->n_blocks = (int)(slots * gz);
     }
     out->u_part_elems = (long long)(out->n_chunks / out->cpb) * q.S;   // one row per workgroup of the slab axis
-    out->v_part_elems = (long long)out->n_zchunks * q.M * q.Ps;
+    out->v_part_elems = (long long)out->n_zchunks * q.vq * q.M * q.Ps;   // layers: z-chunks x row parts (LaneMap<16>)
     // rows of the sweep's slices, then DFX_EW_MAXBLOCKS rows for dfx_post_sweep's own partials (which must not
     // overlap the rows it folds); the element-wise entry points use rows [0, DFX_EW_MAXBLOCKS)
     long long rows = (long long)out->n_blocks * DFX_MAX_SLICES + DFX_EW_MAXBLOCKS;
@@ -2323,11 +2419,16 @@ int dfx_sweep_factored(int32_t mode, const dfx_geom *g, const dfx_plan *pl, floa
 static int resid_update_impl(const Geo &q, float *ra, float *rb, const float *A, const float *B, float sa, float sb,
                              float coef_host, const double *coef_dev, int32_t accumulate, double *zab, double *scal,
                              double *part, int beta_mode, double eps, hipStream_t st) {
-    const int groups = (int)((q.Ps + 15) / 16);
+    const bool wide = q.r >= 16;   // a workgroup per block instead of a thread per block
+    const int groups = wide ? (int)q.Ps : (int)((q.Ps + 15) / 16);
     const int nba = groups < DFX_EW_MAXBLOCKS / 2 ? groups : DFX_EW_MAXBLOCKS / 2;
     const int nbb = q.M < DFX_EW_MAXBLOCKS / 2 ? q.M : DFX_EW_MAXBLOCKS / 2;
-    hipLaunchKernelGGL(k_resid_az, dim3(nba), dim3(256), 0, st, ra, A, zab, q, sa, coef_host, coef_dev, accumulate,
-                       part);
+    if (wide)
+        hipLaunchKernelGGL(k_resid_az_wide, dim3(nba), dim3(256), 0, st, ra, A, zab, q, sa, coef_host, coef_dev,
+                           accumulate, part);
+    else
+        hipLaunchKernelGGL(k_resid_az, dim3(nba), dim3(256), 0, st, ra, A, zab, q, sa, coef_host, coef_dev, accumulate,
+                           part);
     DFX_LAUNCH_CHECK("dfx_resid_update(a)");
     hipLaunchKernelGGL(k_resid_b, dim3(nbb), dim3(256), 0, st, rb, B, (const double *)zab, q.M, (int)q.Ps, sb,
                        coef_host, coef_dev, accumulate, part + (long long)nba * DFX_NPART);
@@ -2601,8 +2702,9 @@ int dfx_post_sweep(const dfx_geom *g, const dfx_plan *pl, const float *u_part, f
     if (!scal || !part) return fail(DFX_EINVAL, "dfx_post_sweep: NULL buffer");
     if ((flags & DFX_POST_U) && (!u_part || !u)) return fail(DFX_EINVAL, "dfx_post_sweep: DFX_POST_U needs u_part, u");
     if ((flags & DFX_POST_V) && !v_part) return fail(DFX_EINVAL, "dfx_post_sweep: DFX_POST_V needs v_part");
-    if ((flags & DFX_POST_V) && pl->n_zchunks > 1 && !v && !(flags & DFX_POST_V_SUMMED))
-        return fail(DFX_EINVAL, "dfx_post_sweep: more than one z-chunk: v needed to hold the sum");
+    const int v_layers = pl->n_zchunks * q.vq;
+    if ((flags & DFX_POST_V) && v_layers > 1 && !v && !(flags & DFX_POST_V_SUMMED))
+        return fail(DFX_EINVAL, "dfx_post_sweep: v_part has more than one layer: v needed to hold the sum");
     if ((flags & DFX_POST_FOLD_SWEEP) && (flags & DFX_POST_FOLD_ADAM))
         return fail(DFX_EINVAL, "dfx_post_sweep: fold either the sweep's or the Adam step's rows");
     if (n_slices < 1 || n_slices > DFX_MAX_SLICES) return fail(DFX_EINVAL, "dfx_post_sweep: bad n_slices");
@@ -2610,7 +2712,7 @@ int dfx_post_sweep(const dfx_geom *g, const dfx_plan *pl, const float *u_part, f
     a.u_part = u_part;
     a.u = u;
     // DFX_POST_V_SUMMED: `v_part` already holds the summed (and, when sharded, all-reduced) v: only ||v||^2 is taken
-    const bool summed = (flags & DFX_POST_V_SUMMED) || pl->n_zchunks == 1;
+    const bool summed = (flags & DFX_POST_V_SUMMED) || v_layers == 1;
     a.v_part = v_part;
     a.v = summed ? nullptr : v;
     a.scal = scal;
@@ -2619,7 +2721,7 @@ int dfx_post_sweep(const dfx_geom *g, const dfx_plan *pl, const float *u_part, f
     a.S = q.S;
     a.vlen = (long long)q.M * q.Ps;
     a.n_urows = pl->n_chunks / pl->cpb;
-    a.n_zchunks = pl->n_zchunks;
+    a.n_zchunks = v_layers;
     a.nbu = 0;
     a.nbv = 0;
     if (flags & DFX_POST_U) {
@@ -2668,7 +2770,7 @@ int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, flo
     if (m_lo < 0 || m_hi > q.M || m_lo >= m_hi) return fail(DFX_EINVAL, "dfx_reduce_v: bad slab range");
     const long long len = (long long)q.M * q.Ps;
     hipLaunchKernelGGL(k_reduce_v, dim3(ew_blocks((m_hi - m_lo) * q.Ps, 1)), dim3(256), 0, (hipStream_t)stream, v_part,
-                       v, (long long)m_lo * q.Ps, (long long)m_hi * q.Ps, len, pl->n_zchunks);
+                       v, (long long)m_lo * q.Ps, (long long)m_hi * q.Ps, len, pl->n_zchunks * q.vq);
     DFX_LAUNCH_CHECK("dfx_reduce_v");
     return 0;
 }

@@ -53,9 +53,10 @@ class HipKernels:
         self.u_part = torch.empty(self.plan.u_part_elems, dtype=torch.float32, device=dev)
         self.v_part = torch.empty(self.plan.v_part_elems, dtype=torch.float32, device=dev)
         self.u = torch.empty((n_z_local, X, Y), dtype=torch.float32, device=dev)
-        # with one z-chunk the sweep writes v directly: no reduce pass, v aliases v_part
+        # with one layer in v_part (one z-chunk, no row parts) the sweep writes v directly: no reduce pass, v aliases v_part
+        self.v_layers = self.plan.v_part_elems // (self.M * self.Xs * self.Ys)
         self._v_own = (torch.empty((n_t, n_l, self.Xs, self.Ys), dtype=torch.float32, device=dev)
-                       if self.plan.n_zchunks > 1 else None)
+                       if self.v_layers > 1 else None)
         self.v = self._v_own if self._v_own is not None else self.v_part.view(n_t, n_l, self.Xs, self.Ys)
         self.ra = self.rb = self.zab = None   # factored residual (new_factored_residual)
         self._last_slices = 1                 # launches the last sweep was cut into (post_sweep folds that many row sets)

@@ -39,8 +39,11 @@ typedef struct dfx_geom {
 } dfx_geom;
 
 /* Launch plan + workspace sizes for one geometry.  fast=1: float4 wave-tile kernels
- * (Y % 4 == 0 and r in {2, 4, 8} - or, through a general tile, {3, 5, 7, 16}; small-space rows B / v_part
- * 8-byte aligned when r = 2); fast=0: shape-generic kernels (any r, any Y). */
+ * (Y % 4 == 0 and r in {2, 4, 8}, the row-part tile's {16, 32, 64} - or, through a general tile, {3, 5, 7};
+ * small-space rows B / v_part 8-byte aligned when r = 2); fast=0: shape-generic kernels (any r, any Y).
+ * v_part holds LAYERS of nT*nL*Xs*Ys floats that dfx_post_sweep / dfx_reduce_v add up: one per z-chunk, times r / 4
+ * for r in {16, 32, 64} (the r / 4 waves that share a block write a layer each); layers = v_part_elems /
+ * (nT*nL*Xs*Ys).  With ONE layer v_part is v itself. */
 typedef struct dfx_plan {
     int32_t fast;
     int32_t zc;          /* z planes a workgroup keeps in registers */
@@ -51,7 +54,7 @@ typedef struct dfx_plan {
     int32_t n_blocks;    /* workgroups per sweep / bcast launch */
     int32_t zs;          /* planes per z-chunk: ceil(nZ / n_zchunks) <= zc (chunks are balanced) */
     int64_t u_part_elems;    /* floats: (n_chunks / cpb) * nZ*X*Y: one row per workgroup of the slab axis */
-    int64_t v_part_elems;    /* floats: n_zchunks * nT*nL*Xs*Ys */
+    int64_t v_part_elems;    /* floats: layers * nT*nL*Xs*Ys, layers = n_zchunks (x r / 4 for r in {16, 32, 64}) */
     int64_t part_elems;      /* doubles: (n_blocks * DFX_MAX_SLICES + DFX_EW_MAXBLOCKS) * DFX_NPART */
 } dfx_plan;
 
@@ -88,7 +91,7 @@ enum { DFX_LAST_NO = 0, DFX_LAST_FOLD = 1, /* final slice: fold PP, XX, XP with 
        DFX_LAST_NOFOLD = 2 /* final slice: leave the partial rows to dfx_post_sweep(DFX_POST_FOLD_SWEEP) */ };
 /* dfx_post_sweep flags */
 enum { DFX_POST_U = 1,           /* u = sum of the u_part rows, UU                                            */
-       DFX_POST_V = 2,           /* v = sum of the v_part z-chunks (if more than one), VV                     */
+       DFX_POST_V = 2,           /* v = sum of the v_part layers (if more than one), VV                       */
        DFX_POST_V_SUMMED = 4,    /* with DFX_POST_V: `v_part` is the finished v (e.g. after the all-reduce)    */
        DFX_POST_FOLD_SWEEP = 8,  /* PP, XX, XP from the rows of a sweep issued with DFX_LAST_NOFOLD            */
        DFX_POST_FOLD_ADAM = 16,  /* ADAM_DD, ADAM_XX from the rows of dfx_adam_step*(DFX_ADAM_NOFOLD)          */
@@ -118,7 +121,7 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc, int32
  * called from the closure A fusion.py:423-426; the axpy `x + p*alpha` fusion.py:445; the
  * direction update fusion.py:455; the dot products / norms of fusion.py:250-251,444).
  * alpha, beta are read from scal[DFX_S_ALPHA], scal[DFX_S_BETA] on the device.
- * Outputs: u_part [n_chunks/cpb][nZ][X][Y], v_part [n_zchunks][nT*nL][Xs][Ys], scal[PP, XX, XP]. */
+ * Outputs: u_part [n_chunks/cpb][nZ][X][Y], v_part [layers][nT*nL][Xs][Ys], scal[PP, XX, XP]. */
 int dfx_sweep(int32_t mode, const dfx_geom *g, const dfx_plan *pl, float *x, const float *r, float *p,
               double *scal, float *u_part, float *v_part, double *part, void *stream);
 
@@ -174,7 +177,7 @@ int dfx_resid_cg_step(const dfx_geom *g, float *ra, float *rb, const float *u, c
  * fusion.py:44-51,89-98,444; one one-workgroup launch that folds those partials, the sweep's (or fused Adam step's)
  * per-workgroup scalar partials, and computes alpha (fusion.py:444, dfx_cg_alpha) - same arithmetic, fixed order.
  * `part` is the buffer the preceding sweep wrote its rows into; n_slices = the number of launches that sweep was cut
- * into.  v may be NULL with one z-chunk (v_part IS v). */
+ * into.  v may be NULL with one layer in v_part (v_part IS v). */
 int dfx_post_sweep(const dfx_geom *g, const dfx_plan *pl, const float *u_part, float *u, const float *v_part,
                    float *v, double *scal, double *part, int32_t n_slices, int32_t flags, double c1, double c2,
                    double eps, void *stream);

@@ -71,9 +71,10 @@ int main() {
                         v[(long long)m * Ps + (xi / r) * Ys + yi / r] += val;
                     }
     };
-    auto fetch_v = [&](std::vector<float> &out) -> int {   // v = sum of the z-chunk partials
+    const long long v_layers = pl.v_part_elems / (M * Ps);   // z-chunks (x row parts for r = 16, 32, 64)
+    auto fetch_v = [&](std::vector<float> &out) -> int {   // v = sum of the layers of v_part
         const float *src = v_part;
-        if (pl.n_zchunks > 1) {
+        if (v_layers > 1) {
             DFX_OK(dfx_reduce_v(&g, &pl, v_part, dv, 0, M, nullptr));
             src = dv;
         }
@@ -137,7 +138,7 @@ int main() {
         h0[DFX_S_RSOLD] = 3.25, h0[DFX_S_ALPHA] = 0.125;
         HIP_OK(hipMemcpy(scal, h0.data(), DFX_NSCAL * 8, hipMemcpyHostToDevice));
         // u, v on the device are u(p), v(p) of step 2 (hu, hv hold them); ra, rb as uploaded
-        const float *v_dev = pl.n_zchunks > 1 ? dv : v_part;
+        const float *v_dev = v_layers > 1 ? dv : v_part;
         DFX_OK(dfx_resid_cg_step(&g, dra, drb, du, v_dev, c1, c2, eps, 1, zab, scal, part, nullptr));
         std::vector<float> gra(S), grb(M * Ps);
         HIP_OK(hipMemcpy(gra.data(), dra, S * 4, hipMemcpyDeviceToHost));
@@ -163,7 +164,7 @@ int main() {
         HIP_OK(hipMemcpy(gp.data(), dp, N * 4, hipMemcpyDeviceToHost));
         DFX_OK(dfx_sweep_factored(DFX_SWEEP_XP, &g, &pl, dx, dra, drb, dp, scal, u_part, v_part, part, 0, pl.cpb, 0,
                                   DFX_LAST_NOFOLD, nullptr));
-        DFX_OK(dfx_post_sweep(&g, &pl, u_part, du, v_part, pl.n_zchunks > 1 ? dv : nullptr, scal, part, 1,
+        DFX_OK(dfx_post_sweep(&g, &pl, u_part, du, v_part, v_layers > 1 ? dv : nullptr, scal, part, 1,
                               DFX_POST_U | DFX_POST_V | DFX_POST_FOLD_SWEEP | DFX_POST_ALPHA, c1, c2, eps, nullptr));
         const double al = 0.125, be = hs[DFX_S_BETA];
         double pp = 0, xxn = 0, xp = 0;
@@ -179,7 +180,7 @@ int main() {
         project(wantp, ru, rv);
         HIP_OK(hipMemcpy(hu.data(), du, S * 4, hipMemcpyDeviceToHost));
         hv.resize(M * Ps);
-        HIP_OK(hipMemcpy(hv.data(), pl.n_zchunks > 1 ? dv : v_part, M * Ps * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hv.data(), v_layers > 1 ? dv : v_part, M * Ps * 4, hipMemcpyDeviceToHost));
         ok = ok && check("u(p) via dfx_post_sweep", hu, ru) && check("v(p) via dfx_post_sweep", hv, rv);
         HIP_OK(hipMemcpy(hs.data(), scal, DFX_NSCAL * 8, hipMemcpyDeviceToHost));
         double uu2 = 0, vv2 = 0;
@@ -194,13 +195,13 @@ int main() {
              std::fabs(hs[DFX_S_ALPHA] - alpha_w) <= 1e-6 * std::fabs(alpha_w);
         // 4. the entry point that takes no workspace gives what the one with a workspace gives
         std::vector<float> a1(S), b1(M * Ps), a2(S), b2(M * Ps);
-        DFX_OK(dfx_resid_update(&g, dra, drb, du, pl.n_zchunks > 1 ? dv : v_part, 0.3f, -0.7f, 1.5f, nullptr, 0, zab, scal,
+        DFX_OK(dfx_resid_update(&g, dra, drb, du, v_layers > 1 ? dv : v_part, 0.3f, -0.7f, 1.5f, nullptr, 0, zab, scal,
                                 part, nullptr));
         HIP_OK(hipMemcpy(a1.data(), dra, S * 4, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(b1.data(), drb, M * Ps * 4, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(hs.data(), scal, DFX_NSCAL * 8, hipMemcpyDeviceToHost));
         const double rr1 = hs[DFX_S_RR];
-        DFX_OK(dfx_resid_update_noalloc(&g, dra, drb, du, pl.n_zchunks > 1 ? dv : v_part, 0.3f, -0.7f, 1.5f, nullptr, 0,
+        DFX_OK(dfx_resid_update_noalloc(&g, dra, drb, du, v_layers > 1 ? dv : v_part, 0.3f, -0.7f, 1.5f, nullptr, 0,
                                         scal, nullptr));
         HIP_OK(hipMemcpy(a2.data(), dra, S * 4, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(b2.data(), drb, M * Ps * 4, hipMemcpyDeviceToHost));

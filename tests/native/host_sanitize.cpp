@@ -14,7 +14,7 @@ int main() {
         return lo + (int)((seed >> 33) % (unsigned)(hi - lo + 1));
     };
     for (int it = 0; it < 20000; ++it) {
-        const int r = (int[]){1, 2, 3, 4, 4, 4, 8, 5}[rnd(0, 7)];
+        const int r = (int[]){1, 2, 3, 4, 4, 4, 8, 5, 16, 32}[rnd(0, 9)];
         dfx_geom g = {rnd(1, 600), rnd(1, 40), rnd(1, 40), (int64_t)r * rnd(1, 160), (int64_t)r * rnd(1, 160), r, 0};
         dfx_plan pl;
         const int tb = (int[]){0, 1, 64, 256, 304, 2048}[rnd(0, 5)];
@@ -25,7 +25,7 @@ int main() {
         if (pl.fast) {
             if ((long long)pl.zs * pl.n_zchunks < g.nZ || (long long)pl.steps * pl.n_chunks < M || pl.zs > pl.zc ||
                 pl.n_chunks % pl.cpb || pl.u_part_elems != (long long)(pl.n_chunks / pl.cpb) * S ||
-                pl.v_part_elems != (long long)pl.n_zchunks * M * Ps)
+                pl.v_part_elems != (long long)pl.n_zchunks * ((r == 16 || r == 32 || r == 64) ? r / 4 : 1) * M * Ps)
                 { std::printf("inconsistent fast plan\n"); ++bad; }
         } else if (pl.n_zchunks != 1 || pl.cpb != 1 || pl.n_chunks < 1 || pl.n_chunks > M || (long long)pl.steps * pl.n_chunks < M ||
                    pl.n_blocks % pl.n_chunks || pl.u_part_elems != (long long)pl.n_chunks * S) { std::printf("inconsistent generic plan\n"); ++bad; }

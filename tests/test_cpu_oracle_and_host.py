@@ -151,7 +151,8 @@ def test_header_constants_match_python_mirror():
                                        ((64, 16, 20, 128, 128, 4), 1), ((8, 4, 4, 32, 32, 4), 1), ((6, 5, 3, 24, 24, 4), 1),
                                        ((4, 3, 2, 16, 16, 2), 1), ((3, 2, 11, 64, 128, 4), 1), ((4, 2, 3, 32, 32, 8), 1),
                                        ((2, 2, 2, 10, 6, 2), 0), ((2, 2, 2, 9, 15, 3), 0), ((7, 3, 5, 6, 132, 2), 1),
-                                       ((2, 3, 9, 24, 40, 8), 1)])
+                                       ((2, 3, 9, 24, 40, 8), 1), ((3, 2, 9, 32, 48, 16), 1), ((2, 2, 3, 64, 96, 32), 1),
+                                       ((2, 1, 2, 64, 128, 64), 1)])
 def test_planner_covers_geometry(dims, fast):
     """dfx_plan_make is host-only code: runs without a GPU."""
     from datafusion_amd import _cabi as cabi
@@ -165,10 +166,14 @@ def test_planner_covers_geometry(dims, fast):
     else:
         assert p.n_zchunks == 1 and p.cpb == 1 and 1 <= p.n_chunks <= n_t * n_l and p.n_blocks % p.n_chunks == 0
     assert p.u_part_elems == (p.n_chunks // max(p.cpb, 1)) * n_z * X * Y
-    assert p.v_part_elems == p.n_zchunks * n_t * n_l * (X // r) * (Y // r)
+    row_parts = r // 4 if r in (16, 32, 64) else 1       # LaneMap<16>: the r / 4 waves of a block write a layer each
+    assert p.v_part_elems == p.n_zchunks * row_parts * n_t * n_l * (X // r) * (Y // r)
     assert p.part_elems >= max(p.n_blocks, cabi.EW_MAXBLOCKS) * cabi.NPART
     if fast:
-        wt = -(-(X // r) * (Y // r) // {2: 64, 4: 16, 8: 4}[r])          # wave tiles per plane: 64 / 16 / 4 blocks each
+        if r in (16, 32, 64):
+            wt = (X // r) * -(-Y // 64) * (r // 4)                        # bands x column groups of 64 x row parts
+        else:
+            wt = -(-(X // r) * (Y // r) // {2: 64, 4: 16, 8: 4}[r])      # wave tiles per plane: 64 / 16 / 4 blocks each
         assert p.cpb >= 1 and p.n_blocks == -(-wt // 4) * p.n_zchunks * -(-p.n_chunks // p.cpb)
 
 

@@ -276,18 +276,24 @@ def test_sliced_sweep_is_bitwise_identical():
                                   # widest tiles, lanes of three tile rows summing blocks (r = 3), a one-block wave (r = 16)
                                   (2, 2, 2, 9, 12, 3), (3, 2, 5, 12, 96, 3), (2, 3, 9, 15, 180, 3), (2, 2, 3, 10, 60, 5),
                                   (3, 1, 7, 18, 48, 6), (2, 2, 4, 14, 56, 7), (2, 1, 3, 20, 40, 10), (2, 2, 5, 24, 36, 12),
-                                  (3, 2, 9, 32, 80, 16), (5, 3, 6, 120, 120, 6), (2, 2, 2, 9, 18, 9)])
+                                  (3, 2, 9, 32, 80, 16), (5, 3, 6, 120, 120, 6), (2, 2, 2, 9, 18, 9),
+                                  # row-part tile (LaneMap<16>: r = 16, 32, 64): one block, a ragged last column group,
+                                  # two z-chunks x r / 4 layers of v_part, waves of one workgroup in different bands (r = 16
+                                  # with an odd number of column groups), a block wider than... the 64-column group (r = 64)
+                                  (2, 2, 3, 16, 16, 16), (3, 2, 17, 48, 208, 16), (2, 3, 5, 64, 96, 32), (3, 1, 4, 32, 160, 32),
+                                  (2, 2, 9, 64, 64, 64), (1, 3, 2, 128, 192, 64), (67, 2, 4, 16, 144, 16)])
 def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     """Every 5-D kernel against torch float64 formulas on shapes the solver tests cannot reach (X != Y, one wave
     tile, inactive waves in the last workgroup, fewer slabs than workgroups, ragged z-chunks, block rows that wrap inside
-    a wave, a plane smaller than a wave; r = 2, 4, 8 and - through the general tile - 3, 5, 7, 16 with Y % 4 == 0 take
-    the fast kernels, everything else the generic ones: float4 lanes when the slab length is a multiple of 4, else scalar)."""
+    a wave, a plane smaller than a wave; r = 2, 4, 8, the row-part tile's 16, 32, 64 and - through the general tile - 3, 5, 7
+    with Y % 4 == 0 take the fast kernels, everything else the generic ones: float4 lanes when the slab length is a multiple of 4, else scalar)."""
     from datafusion_amd import _cabi as cabi
     from datafusion_amd.kernels import HipKernels
     torch.manual_seed(2)
     n_t, n_l, n_z, X, Y, r = dims
     k = HipKernels(n_t, n_l, n_z, X, Y, r, DEV)
-    assert k.plan.fast == (1 if r in (2, 4, 8, 3, 5, 7, 16) and Y % 4 == 0 else 0)
+    assert k.plan.fast == (1 if r in (2, 4, 8, 3, 5, 7, 16, 32, 64) and Y % 4 == 0 else 0)
+    assert k.v_layers == k.plan.n_zchunks * (r // 4 if r in (16, 32, 64) else 1)
     x, rr, p = (torch.randn(k.shape, device=DEV) for _ in range(3))
     al, be = 0.37, -0.61
     k.scal[cabi.S_ALPHA], k.scal[cabi.S_BETA] = al, be

@@ -189,10 +189,11 @@ def test_readme_flow_at_its_stated_size(tmp_path):
 
 @pytest.mark.parametrize("dims", [(5, 3, 6, 32, 64, 4), (4, 2, 9, 48, 16, 4), (3, 3, 5, 24, 40, 8), (6, 2, 4, 20, 36, 2),
                                   (3, 2, 3, 18, 30, 3), (4, 3, 5, 24, 36, 3), (3, 2, 4, 30, 60, 5), (2, 3, 9, 18, 96, 6),
-                                  (2, 3, 3, 28, 56, 7), (3, 2, 3, 32, 48, 16)])
+                                  (2, 3, 3, 28, 56, 7), (3, 2, 3, 32, 48, 16), (2, 3, 10, 48, 80, 16), (3, 2, 5, 64, 96, 32),
+                                  (2, 2, 3, 64, 128, 64)])
 def test_solver_on_non_square_planes_vs_the_oracle(dims):
     """X != Y through the whole solver (the reference's baseline() assumes square planes, baseline.py:38, but its CG
-    does not: init_type="random"), both residual representations, fast path (r = 2, 4, 8; general tile r = 3, 5, 7, 16)
+    does not: init_type="random"), both residual representations, fast path (r = 2, 4, 8; row-part tile r = 16, 32, 64; general tile r = 3, 5, 7)
     and generic path (r = 6, or Y % 4 != 0), unequal weights, against the eager oracle."""
     from datafusion_amd import FusionCG
     n_t, n_l, n_z, X, Y, r = dims
@@ -203,7 +204,7 @@ def test_solver_on_non_square_planes_vs_the_oracle(dims):
     xo = O.cg(O.prepare(spc, cmos, weights=w, init_type="random", tol=None), 6, with_loss=False)
     for residual in ("factored", "explicit"):
         f = FusionCG(spc, cmos, weights=w, init_type="random", tol=None, device=DEV, residual=residual)
-        assert f.k.plan.fast == (1 if Y % 4 == 0 and r in (2, 4, 8, 3, 5, 7, 16) else 0)
+        assert f.k.plan.fast == (1 if Y % 4 == 0 and r in (2, 4, 8, 3, 5, 7, 16, 32, 64) else 0)
         x, _, _ = f(6, return_numpy=False)
         assert float(O.rel_l2(x.cpu(), xo)) <= TIGHT, (dims, residual)
 

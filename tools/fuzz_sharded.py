@@ -32,7 +32,7 @@ def worker(rank, port, cases, seed, q, general_r=False):
     worst, failed = 0.0, []
     for case in range(cases):
         world = rng.choice([2, 3, 3])
-        r = rng.choice([3, 5, 6, 7, 10, 12, 16] if general_r else [2, 4, 4, 4, 8, 3])
+        r = rng.choice([3, 5, 6, 7, 10, 12, 16, 16, 32] if general_r else [2, 4, 4, 4, 8, 3])
         xs = rng.randint(1, 48 // r)
         if general_r:
             xs = 4 * rng.randint(1, max(1, 24 // r))      # Y = xs r a multiple of 4: the general-r tile (LaneMap<0>)
