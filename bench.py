@@ -47,6 +47,9 @@ WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "c2r12": (256, 16, 16, 120, 12),
     "c2r16": (256, 16, 16, 128, 16),     # row-part tile (LaneMap<16>: r = 16, 32, 64)
     "c2r32": (256, 16, 16, 128, 32),
+    "c2y120": (256, 16, 16, 120, 4),     # r = 4 on planes whose rows are not 128-byte aligned (480 B pitch)
+    "c2r3y96": (256, 16, 28, 96, 3),     # strip tile on 128-byte aligned rows (384 / 768 B pitch)
+    "c2r3y192": (256, 16, 7, 192, 3),
     "c2gen": (256, 16, 16, 126, 3),      # Y % 4 != 0: the generic kernels (flat float4 sweep + the v pass)
     "c2odd": (256, 16, 15, 125, 5),      # slab length not a multiple of 4: the generic kernels with scalar lanes
     "p512s": (16, 4, 16, 512, 4),        # wide planes (more workgroups than CUs) with few / many slabs per workgroup

@@ -79,27 +79,37 @@ struct Geo {
     int nZ, X, Y, Xs, Ys, r;
     int WT;        // wave tiles per plane (fast path): ceil(nblk / BW), BW = 64, 16, 4 blocks per wave for r = 2, 4, 8;
                    // general r (LaneMap<0>): Xs * gTPR
-    int gL;        // general r: lanes (float4) per tile row, 0 when r has no such tile; tile = r rows x 4 gL columns
-    int gTPR;      // general r: tiles per band of r rows = ceil(Y / (4 gL)); row-part tile: column groups ceil(Y / 64)
-    int vq;        // row-part tile (LaneMap<16>: r = 16, 32, 64): r / 4 waves share a block, each writes its own layer of
-                   // v_part; 1 for every other map.  v_part holds n_zchunks * vq layers of M * Ps floats.
+    int gL;        // strip tile (LaneMap<0>, general r): lanes (float4) per tile row, 0 when r has no such tile; the tile is
+                   // 4 rows x 4 gL columns (a multiple of r and of 4)
+    int gTPR;      // strip tile: column groups per strip = ceil(Y / (4 gL)); row-part tile: column groups ceil(Y / 64)
+    int vq;        // layers of v_part per z-chunk.  Row-part tile (LaneMap<16>: r = 16, 32, 64): the r / 4 waves that share a
+                   // block write a layer each; strip tile: the 4-row strips that meet a block row write layer strip % vq
+                   // (vq = the most strips a block row meets); 1 for the r = 2, 4, 8 maps and the generic kernels.
+                   // v_part holds n_zchunks * vq layers of M * Ps floats; block row xb is the sum of the layers
+                   // s % vq, s = floor(xb r / 4) .. floor((xb r + r - 1) / 4), of every z-chunk.
     int nblk;      // r x r blocks per plane = Xs*Ys
     int zs;        // planes per z-chunk of the plan in use (<= the kernel's ZC); set by the entry points
 };
 
-// General r (LaneMap<0>): a wave covers one band of r rows x TC = 4 L columns, one float4 per lane, with L the largest
-// multiple of r / gcd(4, r) such that r L <= 64 lanes - then TC is a multiple of r and a tile holds whole blocks.
-// r = 3: 3 x 84 (63 lanes), 5: 5 x 40 (50), 7: 7 x 28 (49), 16: 16 x 16 (64) [6: 6 x 36, 10: 10 x 20, 12: 12 x 12 exist but lose
-// to the generic kernels]; 0 sends the geometry to the generic kernels.
+// Strip tile (LaneMap<0>, general r): a wave covers 4 rows x CW columns, CW = 4 L the largest multiple of lcm(r, 4) that
+// is <= 64 - whole blocks in y, whole float4s, 4 L of the 64 lanes at work (r = 3, 5, 6, 10, 12, 15, 20, 30: 60; 7, 14, 28:
+// 56; 13, 26: 52; 24, 48: 48; 11, 22, 44: 44; 9, 18, 36: 36).  0 sends the geometry to the generic kernels.
 int general_lanes_per_row(int r) {
     static const bool off = getenv("DFX_NO_GENERAL_TILE") != nullptr;   // measurement knob: send every such r to the generic kernels
-    if (off) return 0;
-    // the tile is used where it beats the generic kernels (flat float4 sweep + a separate v pass, any r): measured on
-    // the C2 volume, tile / generic, r = 3: 3.39 / 3.73 ms, 5: 3.42 / 3.67, 7: 2.96 / 3.29, 16: 3.16 / 3.82 - but
-    // 6: 3.74 / 3.64, 10: 3.71 / 3.62, 12: 4.52 / 3.64 (few lanes per tile row, short row segments)
-    if (!(r == 3 || r == 5 || r == 7 || r == 16)) return 0;
-    const int g = (r % 4 == 0) ? 4 : (r % 2 == 0 ? 2 : 1), q = r / g;
-    return (64 / r) / q * q;
+    if (off || r < 2) return 0;
+    const int g = (r % 4 == 0) ? 4 : (r % 2 == 0 ? 2 : 1);
+    const int l = r / g * 4;            // lcm(r, 4)
+    if (l > 64) return 0;
+    return (64 / l) * l / 4;
+}
+// the most 4-row strips a block row of r rows meets
+int strip_layers(int r, int Xs) {
+    int most = 1;
+    for (int xb = 0; xb < Xs && xb < 4; ++xb) {
+        const int n = (xb * r + r - 1) / 4 - (xb * r) / 4 + 1;
+        if (n > most) most = n;
+    }
+    return most;
 }
 
 // Row-part tile (LaneMap<16>): r = 16, 32, 64 with the wave shape of r = 4 (4 rows x 64 columns, 256 B row segments);
@@ -132,10 +142,14 @@ int make_geo(const dfx_geom *g, Geo *o) {
     o->nblk = o->Xs * o->Ys;
     o->gL = o->gTPR = 0;
     o->vq = 1;
-    if (o->r == 2 || o->r == 4 || o->r == 8) {
+    // the r = 2, 4, 8 and row-part maps stream with non-temporal accesses, which need plane rows that start on 128-byte
+    // lines (Y % 32 == 0): r = 4 on 120 x 120 planes ran at 0.34 of peak (every partial line fetched twice).  Other widths
+    // take the strip tile, whose accesses go through the L2.
+    const bool aligned_rows = (o->Y % 32) == 0 || getenv("DFX_NT_ANY_WIDTH") != nullptr;
+    if ((o->r == 2 || o->r == 4 || o->r == 8) && (aligned_rows || !general_lanes_per_row(o->r) || (o->Y % 4) != 0)) {
         const int bw = o->r == 2 ? 64 : (o->r == 8 ? 4 : 16);   // LaneMap<R>::BW
         o->WT = (o->nblk + bw - 1) / bw;
-    } else if (rowpart_tile(o->r)) {
+    } else if (rowpart_tile(o->r) && (aligned_rows || !general_lanes_per_row(o->r))) {
         o->vq = o->r / 4;
         o->gTPR = (o->Y + 63) / 64;
         const long long wt = (long long)o->Xs * o->gTPR * o->vq;
@@ -143,8 +157,16 @@ int make_geo(const dfx_geom *g, Geo *o) {
         o->WT = (int)wt;
     } else {
         o->gL = general_lanes_per_row(o->r);
-        o->gTPR = o->gL ? (o->Y + 4 * o->gL - 1) / (4 * o->gL) : 0;
-        o->WT = o->Xs * o->gTPR;
+        if (o->gL && (o->Y % 4) == 0) {
+            o->gTPR = (o->Y + 4 * o->gL - 1) / (4 * o->gL);
+            const long long wt = (long long)((o->X + 3) / 4) * o->gTPR;
+            if (wt > 0x7fffffffLL) return fail(DFX_EINVAL, "plane too large");
+            o->WT = (int)wt;
+            o->vq = strip_layers(o->r, o->Xs);
+        } else {
+            o->gL = 0;
+            o->WT = 0;
+        }
     }
     return 0;
 }
@@ -152,6 +174,8 @@ int make_geo(const dfx_geom *g, Geo *o) {
 // Y a multiple of 4 (every plane row 16-byte aligned) and r in {2, 4, 8} - a float4 never straddles a block row
 // (r = 4, 8) or covers exactly two blocks (r = 2), LaneMap<R> - or an r with a general tile (LaneMap<0>: 3, 5, 7, 16).
 bool fast_ok(const Geo &q) { return (q.r == 2 || q.r == 4 || q.r == 8 || q.gL > 0 || q.vq > 1) && (q.Y % 4) == 0; }
+// which lane map a fast plan uses: the r = 2, 4, 8 maps, the row-part tile (16) or the strip tile (0)
+int lane_map_of(const Geo &q) { return q.gL > 0 ? 0 : (q.vq > 1 ? 16 : q.r); }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -311,12 +335,16 @@ struct LaneMap {
     }
 };
 
-// General r (R = 0: r = 3, 5, 7, 16; see general_lanes_per_row).  A float4 may straddle two blocks (never
-// three: r >= 3), so the block sums go through a wave-private LDS tile instead of shuffles: every lane stores its
-// z-summed float4, the lanes of tile row 0 add the r rows of their four columns (r ds_read_b128), then one lane per block
-// adds its r column sums (r ds_read_b32).  LDS operations of one wave execute in order; the wavefront-scope fences
-// keep the compiler from moving them across each other.  Everything else (u accumulators, ra in registers, 16 B
-// streaming accesses) is the fast path's.
+// Strip tile (R = 0: general r, see general_lanes_per_row).  The wave keeps the shape of r = 4 - 4 rows x CW <= 64
+// columns, wave tiles numbered column groups first, then the 4-row strips of the plane, so that a workgroup touches one
+// contiguous run of rows - whatever r is.  A strip meets one or two block rows (r >= 3) and a float4 one or two blocks,
+// so the block sums go through a wave-private LDS tile instead of shuffles: every lane stores its z-summed float4; the
+// lanes of the strip's first row add, for their four columns, the rows that lie in the upper and in the lower block row;
+// then the active lanes share out the (up to 2 x CW / r) blocks and add r column sums each.  The partial block sums
+// of a strip go to layer strip % vq of v_part (Geo::vq).  LDS operations of one wave execute in order; the wavefront-
+// scope fences keep the compiler from moving them across each other.  Everything else (u accumulators, ra in
+// registers, 16 B accesses) is the fast path's.  (Round 3's first general tile was r rows x 4 L columns with r L <= 64:
+// short row segments, a ragged last tile per band; r = 3 / 5 / 7 ran at 0.55 of peak.)
 template <>
 struct LaneMap<0> {
     bool act;
@@ -324,49 +352,64 @@ struct LaneMap<0> {
     int bi;           // small-space index (inside a plane of Xs x Ys) of the block under the float4's first element
     int cut;          // how many of the four elements lie in that block (the rest in block bi + 1); >= 4: all
     int lds;          // this lane's float4 in the wave's LDS tile (floats)
-    int TC, r, rows;  // tile width (floats), block size, tile rows (= r)
-    int csum;         // >= 0: this lane adds the r rows of columns [csum, csum + 4) of the tile
-    int vb, vcol;     // vb >= 0: this lane adds block vb of the small plane from column sums [vcol, vcol + r)
+    int r, strip;
+    int nrows, k;     // live rows of the strip (4, fewer at the bottom of the plane); rows of them in the upper block row
+    int csum;         // >= 0: this lane adds the rows of columns [csum, csum + 4) of the tile
+    int ord, nact;    // ordinal of this lane among the wave's active lanes, and their number
+    int nbc, ncell;   // blocks per block row in this column group; blocks the strip contributes to (nbc or 2 nbc)
+    int vb0;          // small-space index of the strip's first block (upper block row, this column group)
+    int Ys;
     __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
-        const int L = q.gL;
-        r = rows = q.r;
-        TC = 4 * L;
+        const int L = q.gL, CW = 4 * L;
+        r = q.r;
+        Ys = q.Ys;
+        strip = wt / q.gTPR;
+        const int cg = wt - strip * q.gTPR;
         const int dx = lane / L, j = lane - dx * L;
-        const int xb = wt / q.gTPR, tc = wt - xb * q.gTPR;
-        const int col = tc * TC + 4 * j;
-        act = wt < q.WT && dx < r && col < q.Y;
-        off2 = (long long)(xb * r + dx) * q.Y + col;
-        const int yb = col / r;
+        const int R0 = 4 * strip, row = R0 + dx, col = cg * CW + 4 * j;
+        const bool live = wt < q.WT;
+        act = live && dx < 4 && row < q.X && col < q.Y;
+        off2 = (long long)row * q.Y + col;
+        const int xb = row / r, yb = col / r;
         bi = xb * q.Ys + yb;
         cut = r - (col - yb * r);
-        lds = dx * TC + 4 * j;
-        const int yt = min(TC, q.Y - tc * TC);       // live columns of this tile: a multiple of 4 and of r
-        const int apr = yt >> 2, nb = yt / r;         // active lanes per row, blocks in the tile
-        csum = (dx == 0 && j < apr) ? 4 * j : -1;
-        const int o = dx * apr + j;                   // ordinal among the active lanes: the first nb of them sum a block
-        vb = (act && o < nb) ? xb * q.Ys + (tc * TC) / r + o : -1;
-        vcol = o * r;
+        lds = dx * 64 + 4 * j;
+        const int A = R0 / r;
+        nrows = min(4, q.X - R0);
+        k = min(nrows, (A + 1) * r - R0);
+        const int yt = live ? min(CW, q.Y - cg * CW) : 0;   // live columns of this group: a multiple of 4 and of r
+        const int apr = yt >> 2;                               // active lanes per row
+        nbc = yt / r;
+        ncell = (k < nrows) ? 2 * nbc : nbc;
+        csum = (act && dx == 0) ? 4 * j : -1;
+        ord = dx * apr + j;
+        nact = nrows * apr;
+        vb0 = A * q.Ys + (cg * CW) / r;
     }
     __device__ __forceinline__ void vstore(f4 s4, float *vrow, int lane) const {
-        __shared__ __attribute__((aligned(16))) float tile[DFX_WAVES][512];   // r x TC floats (<= 340) + TC column sums
+        __shared__ __attribute__((aligned(16))) float tile[DFX_WAVES][6 * 64];   // 4 rows x 64 floats + 2 rows of column sums
         float *t = tile[threadIdx.x >> 6];
-        float *cs = t + rows * TC;
+        float *cs = t + 4 * 64;
         *reinterpret_cast<f4 *>(t + lds) = s4;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (csum >= 0) {
-            f4 c = *reinterpret_cast<const f4 *>(t + csum);
-            for (int d = 1; d < rows; ++d) c += *reinterpret_cast<const f4 *>(t + d * TC + csum);
-            *reinterpret_cast<f4 *>(cs + csum) = c;
+            f4 up = *reinterpret_cast<const f4 *>(t + csum), lo = {0.f, 0.f, 0.f, 0.f};
+            for (int d = 1; d < k; ++d) up += *reinterpret_cast<const f4 *>(t + d * 64 + csum);
+            for (int d = k; d < nrows; ++d) lo += *reinterpret_cast<const f4 *>(t + d * 64 + csum);
+            *reinterpret_cast<f4 *>(cs + csum) = up;
+            *reinterpret_cast<f4 *>(cs + 64 + csum) = lo;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (vb >= 0) {
-            float s = cs[vcol];
-            for (int d = 1; d < r; ++d) s += cs[vcol + d];
-            vrow[vb] = s;
+        for (int c = ord; c < ncell; c += nact) {
+            const int half = c >= nbc ? 1 : 0, cb = c - half * nbc;
+            const float *src = cs + half * 64 + cb * r;
+            float sum = src[0];
+            for (int d = 1; d < r; ++d) sum += src[d];
+            vrow[vb0 + half * Ys + cb] = sum;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next slab's stores stay behind these reads
         __builtin_amdgcn_wave_barrier();
@@ -379,8 +422,7 @@ struct LaneMap<0> {
 };
 
 // Row-part tile (R = 16: r = 16, 32, 64).  The wave has the shape of r = 4 - 4 rows x 16 float4, 256 B per row segment -
-// and covers a quarter-block-high strip of 64 / r blocks; the r / 4 strips of a band of r rows belong to consecutive
-// wave tiles (the waves of one workgroup for r = 16).  A wave adds its 4 rows x r columns per block with shuffles and
+// and covers a 4-row strip of 64 / r blocks; wave tiles are numbered like r = 4's (column groups, then strips).  A wave adds its 4 rows x r columns per block with shuffles and
 // stores the partial in ITS layer of v_part (layer = z-chunk * r/4 + row part); the layers are added where the
 // z-chunks' are (dfx_post_sweep / dfx_reduce_v).  The general tile's 16 x 16 wave (64 B row segments, cached accesses)
 // ran the C2 volume with r = 16 at 0.68 of peak.
@@ -393,9 +435,11 @@ struct LaneMap<16> {
     int r;
     __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
         r = q.r;
-        part = wt % q.vq;
-        const int t = wt / q.vq;
-        const int xb = t / q.gTPR, cg = t - xb * q.gTPR;
+        // wave tiles in the order of r = 4: column groups fastest, then the 4-row strips of the plane - a workgroup's four
+        // waves touch one contiguous run of rows (2.80 -> ? ms at C2 size against strips of one block first)
+        const int strip = wt / q.gTPR, cg = wt - strip * q.gTPR;
+        const int xb = strip / q.vq;
+        part = strip - xb * q.vq;
         const int dx = lane >> 4, j = lane & 15;
         const int col = cg * 64 + 4 * j;
         act = wt < q.WT && col < q.Y;
@@ -422,6 +466,7 @@ struct LaneMap<16> {
 template <int R>
 __device__ __forceinline__ long long v_layer(const LaneMap<R> &L, const Geo &q) {
     if constexpr (R == 16) return (long long)blockIdx.y * q.vq + L.part;
+    else if constexpr (R == 0) return (long long)blockIdx.y * q.vq + L.strip % q.vq;
     else return (long long)blockIdx.y;
 }
 
@@ -1395,14 +1440,40 @@ __global__ __launch_bounds__(256) void k_reduce_u(const float *u_part, float *u,
     block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
 }
 
-__global__ __launch_bounds__(256) void k_reduce_v(const float *v_part, float *v, long long lo, long long hi,
-                                                  long long len, int n_zchunks) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
-        float s = 0.f;
-        for (int c = 0; c < n_zchunks; ++c) s += v_part[(long long)c * len + i];
-        v[i] = s;
+// The layers of v_part (Geo::vq).  dense: every layer holds every block (z-chunks; the row parts of LaneMap<16>);
+// otherwise (strip tile) block row xb is in the layers s % vq of the strips s that meet it.
+struct VLayers {
+    int nzc, vq, dense, r, Ys;
+    long long Ps, vlen;
+};
+__device__ __forceinline__ float v_layers_sum(const float *v_part, const VLayers &w, long long i) {
+    float s = 0.f;
+    if (w.dense) {
+        for (int c = 0; c < w.nzc * w.vq; ++c) s += v_part[(long long)c * w.vlen + i];
+    } else {
+        const int xb = (int)(i % w.Ps) / w.Ys;
+        const int s0 = (xb * w.r) >> 2, s1 = (xb * w.r + w.r - 1) >> 2;
+        for (int z = 0; z < w.nzc; ++z)
+            for (int t = s0; t <= s1; ++t) s += v_part[((long long)z * w.vq + t % w.vq) * w.vlen + i];
     }
+    return s;
+}
+VLayers v_layers_of(const Geo &q, const dfx_plan *pl) {
+    VLayers w;
+    w.nzc = pl->n_zchunks;
+    w.vq = q.vq;
+    w.dense = (q.vq == 1 || q.gL == 0) ? 1 : 0;   // strip tile: gL > 0
+    w.r = q.r;
+    w.Ys = q.Ys;
+    w.Ps = q.Ps;
+    w.vlen = (long long)q.M * q.Ps;
+    return w;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_v(const float *v_part, float *v, long long lo, long long hi, VLayers w) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride)
+        v[i] = v_layers_sum(v_part, w, i);
 }
 
 // mode 0: sum a^2 ; 1: sum mask*(a-b)^2 ; 2: sum a
@@ -1480,8 +1551,9 @@ struct PostArgs {
     const double *fold_rows;   // the preceding launch's partial rows
     double *part;              // this launch's partial rows
     long long S, vlen;
-    int n_urows, n_zchunks, nbu, nbv, n_fold_rows, flags;
+    int n_urows, n_zchunks, nbu, nbv, n_fold_rows, flags;   // n_zchunks: layers of v_part (z-chunks x Geo::vq)
     double c1, c2, eps;
+    VLayers vl;
 };
 
 __global__ __launch_bounds__(256) void k_post_sweep(const PostArgs a) {
@@ -1511,7 +1583,7 @@ __global__ __launch_bounds__(256) void k_post_sweep(const PostArgs a) {
     } else if (a.flags & DFX_POST_V) {
         const long long stride = (long long)a.nbv * 256;
         const long long t0 = (long long)(b - a.nbu) * 256 + threadIdx.x;
-        const bool vec = (a.vlen % 4 == 0) && ((((uintptr_t)a.v_part | (uintptr_t)a.v) & 15) == 0);
+        const bool vec = (a.vlen % 4 == 0) && ((((uintptr_t)a.v_part | (uintptr_t)a.v) & 15) == 0) && (a.vl.dense || !a.v);
         if (vec) {
             for (long long i = t0; i < a.vlen / 4; i += stride) {
                 f4 sacc = ld4(a.v_part + 4 * i);
@@ -1523,10 +1595,12 @@ __global__ __launch_bounds__(256) void k_post_sweep(const PostArgs a) {
             }
         } else {
             for (long long i = t0; i < a.vlen; i += stride) {
-                float sacc = a.v_part[i];
+                float sacc;
                 if (a.v) {
-                    for (int c = 1; c < a.n_zchunks; ++c) sacc += a.v_part[(long long)c * a.vlen + i];
+                    sacc = v_layers_sum(a.v_part, a.vl, i);
                     a.v[i] = sacc;
+                } else {
+                    sacc = a.v_part[i];
                 }
                 vv += (double)sacc * (double)sacc;
             }
@@ -2128,13 +2202,13 @@ static int solo_lds_bytes() {
     } while (0)
 
 // the fast kernels exist for zc in {4, 8} x r in {2, 4, 8, row-part tile (LaneMap<16>), general (LaneMap<0>)}; check_plan / fast_ok admit nothing else
-#define DFX_DISPATCH_R(ZCV, r, ...)                                        \
+#define DFX_DISPATCH_R(ZCV, lm, ...)                                       \
     do {                                                                   \
         constexpr int ZC_ = ZCV;                                           \
-        if ((r) == 2) { constexpr int R_ = 2; __VA_ARGS__; }               \
-        else if ((r) == 4) { constexpr int R_ = 4; __VA_ARGS__; }          \
-        else if ((r) == 8) { constexpr int R_ = 8; __VA_ARGS__; }          \
-        else if (rowpart_tile(r)) { constexpr int R_ = 16; __VA_ARGS__; }  \
+        if ((lm) == 2) { constexpr int R_ = 2; __VA_ARGS__; }              \
+        else if ((lm) == 4) { constexpr int R_ = 4; __VA_ARGS__; }         \
+        else if ((lm) == 8) { constexpr int R_ = 8; __VA_ARGS__; }         \
+        else if ((lm) == 16) { constexpr int R_ = 16; __VA_ARGS__; }       \
         else { constexpr int R_ = 0; __VA_ARGS__; }                        \
     } while (0)
 #define DFX_DISPATCH_ZC_R(zc, r, ...)                                      \
@@ -2147,9 +2221,9 @@ template <int MODE>
 int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
     dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
     if (MODE != DFX_SWEEP_PROJECT && a.ra)
-        DFX_DISPATCH_ZC_R(pl->zc, a.q.r, DFX_LAUNCH_SOLO((k_sweep_fast<MODE, ZC_, R_, MODE != DFX_SWEEP_PROJECT>), grid, block, st, a));
+        DFX_DISPATCH_ZC_R(pl->zc, lane_map_of(a.q), DFX_LAUNCH_SOLO((k_sweep_fast<MODE, ZC_, R_, MODE != DFX_SWEEP_PROJECT>), grid, block, st, a));
     else
-        DFX_DISPATCH_ZC_R(pl->zc, a.q.r, DFX_LAUNCH_SOLO((k_sweep_fast<MODE, ZC_, R_, false>), grid, block, st, a));
+        DFX_DISPATCH_ZC_R(pl->zc, lane_map_of(a.q), DFX_LAUNCH_SOLO((k_sweep_fast<MODE, ZC_, R_, false>), grid, block, st, a));
     DFX_LAUNCH_CHECK("dfx_sweep(fast)");
     return 0;
 }
@@ -2157,7 +2231,7 @@ int launch_sweep_fast(const SweepArgs &a, const dfx_plan *pl, hipStream_t st) {
 template <bool HAS_IN, bool HAS_MASK>
 int launch_bcast_fast(const BcastArgs &a, const dfx_plan *pl, hipStream_t st) {
     dim3 grid((a.q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
-    DFX_DISPATCH_ZC_R(pl->zc, a.q.r, DFX_LAUNCH_SOLO((k_bcast_fast<ZC_, R_, HAS_IN, HAS_MASK>), grid, block, st, a));
+    DFX_DISPATCH_ZC_R(pl->zc, lane_map_of(a.q), DFX_LAUNCH_SOLO((k_bcast_fast<ZC_, R_, HAS_IN, HAS_MASK>), grid, block, st, a));
     DFX_LAUNCH_CHECK("dfx_bcast(fast)");
     return 0;
 }
@@ -2548,13 +2622,13 @@ static int adam_impl(const dfx_geom *g, const dfx_plan *pl, float *x, float *m1,
         dim3 grid((q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb),
             block(64 * DFX_WAVES);
         if (mask && m1f)
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, true, true>), grid, block, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, lane_map_of(q), DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, true, true>), grid, block, st, a));
         else if (mask)
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, true, false>), grid, block, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, lane_map_of(q), DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, true, false>), grid, block, st, a));
         else if (m1f)
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, true>), grid, block, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, lane_map_of(q), DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, true>), grid, block, st, a));
         else
-            DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, false>), grid, block, st, a));
+            DFX_DISPATCH_ZC_R(pl->zc, lane_map_of(q), DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, false>), grid, block, st, a));
         DFX_LAUNCH_CHECK("dfx_adam_step(fast)");
         n_rows = (slice + 1) * pl->n_blocks;
     } else {
@@ -2663,7 +2737,7 @@ int dfx_adam_apply_project(const dfx_geom *g, const dfx_plan *pl, float *x, cons
                (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
                (flags & DFX_ADAM_NONNEG) ? 1 : 0, q, pl->steps, pl->cpb, 0, pl->cpb, 0, grad};
     dim3 grid((q.WT + DFX_WAVES - 1) / DFX_WAVES, pl->n_zchunks, (pl->n_chunks + pl->cpb - 1) / pl->cpb), block(64 * DFX_WAVES);
-    DFX_DISPATCH_ZC_R(pl->zc, q.r, DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, false, true>), grid, block, st, a));
+    DFX_DISPATCH_ZC_R(pl->zc, lane_map_of(q), DFX_LAUNCH_SOLO((k_adam_fast<ZC_, R_, false, false, true>), grid, block, st, a));
     DFX_LAUNCH_CHECK("dfx_adam_apply_project");
     return 0;   // u, v, ADAM_DD, ADAM_XX, TOL: dfx_post_sweep(DFX_POST_U | DFX_POST_V | DFX_POST_FOLD_ADAM)
 }
@@ -2722,6 +2796,7 @@ int dfx_post_sweep(const dfx_geom *g, const dfx_plan *pl, const float *u_part, f
     a.vlen = (long long)q.M * q.Ps;
     a.n_urows = pl->n_chunks / pl->cpb;
     a.n_zchunks = v_layers;
+    a.vl = v_layers_of(q, pl);
     a.nbu = 0;
     a.nbv = 0;
     if (flags & DFX_POST_U) {
@@ -2768,9 +2843,8 @@ int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, flo
     q.zs = pl->fast ? pl->zs : 1;
     if (!v_part || !v) return fail(DFX_EINVAL, "dfx_reduce_v: NULL buffer");
     if (m_lo < 0 || m_hi > q.M || m_lo >= m_hi) return fail(DFX_EINVAL, "dfx_reduce_v: bad slab range");
-    const long long len = (long long)q.M * q.Ps;
     hipLaunchKernelGGL(k_reduce_v, dim3(ew_blocks((m_hi - m_lo) * q.Ps, 1)), dim3(256), 0, (hipStream_t)stream, v_part,
-                       v, (long long)m_lo * q.Ps, (long long)m_hi * q.Ps, len, pl->n_zchunks * q.vq);
+                       v, (long long)m_lo * q.Ps, (long long)m_hi * q.Ps, v_layers_of(q, pl));
     DFX_LAUNCH_CHECK("dfx_reduce_v");
     return 0;
 }

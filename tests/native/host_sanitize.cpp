@@ -6,6 +6,19 @@
 
 #include "../../include/dfx.h"
 
+// layers of v_part per z-chunk on a fast plan (include/dfx.h): row parts for r = 16, 32, 64 and 1 for r = 2, 4, 8 on
+// planes with 128-byte aligned rows (Y % 32 == 0); else the strip tile: the most 4-row strips a block row meets
+static int layers_per_zchunk(int r, int Xs, long long Y) {
+    if ((r == 2 || r == 4 || r == 8) && Y % 32 == 0) return 1;
+    if ((r == 16 || r == 32 || r == 64) && Y % 32 == 0) return r / 4;
+    int most = 1;
+    for (int xb = 0; xb < Xs && xb < 4; ++xb) {
+        const int n = (xb * r + r - 1) / 4 - (xb * r) / 4 + 1;
+        if (n > most) most = n;
+    }
+    return most;
+}
+
 int main() {
     int bad = 0;
     unsigned long long seed = 12345;
@@ -25,7 +38,7 @@ int main() {
         if (pl.fast) {
             if ((long long)pl.zs * pl.n_zchunks < g.nZ || (long long)pl.steps * pl.n_chunks < M || pl.zs > pl.zc ||
                 pl.n_chunks % pl.cpb || pl.u_part_elems != (long long)(pl.n_chunks / pl.cpb) * S ||
-                pl.v_part_elems != (long long)pl.n_zchunks * ((r == 16 || r == 32 || r == 64) ? r / 4 : 1) * M * Ps)
+                pl.v_part_elems != (long long)pl.n_zchunks * layers_per_zchunk(r, (int)(g.X / r), g.Y) * M * Ps)
                 { std::printf("inconsistent fast plan\n"); ++bad; }
         } else if (pl.n_zchunks != 1 || pl.cpb != 1 || pl.n_chunks < 1 || pl.n_chunks > M || (long long)pl.steps * pl.n_chunks < M ||
                    pl.n_blocks % pl.n_chunks || pl.u_part_elems != (long long)pl.n_chunks * S) { std::printf("inconsistent generic plan\n"); ++bad; }

@@ -147,12 +147,33 @@ def test_header_constants_match_python_mirror():
         assert int(re.search(rf"DFX_SWEEP_{name}\s*=\s*(\d+)", src).group(1)) == i
 
 
+def _v_layers_per_zchunk(r, X, Y):
+    """Layers of v_part per z-chunk (include/dfx.h, dfx_plan): r / 4 row parts for r = 16, 32, 64; for the strip tile
+    (any other r with lcm(r, 4) <= 64 and Y % 4 == 0 - and every r on planes whose rows are not 128-byte aligned, Y % 32 != 0)
+    the most 4-row strips a block row meets; else 1."""
+    import math
+    if Y % 4 or (r in (2, 4, 8) and Y % 32 == 0):
+        return 1
+    if r in (16, 32, 64) and Y % 32 == 0:
+        return r // 4
+    if r < 2 or math.lcm(r, 4) > 64:
+        return 1
+    return max((xb * r + r - 1) // 4 - (xb * r) // 4 + 1 for xb in range(min(X // r, 4)))
+
+
+def _fast_expected(r, Y):
+    import math
+    return 1 if Y % 4 == 0 and r >= 2 and math.lcm(r, 4) <= 64 else 0
+
+
 @pytest.mark.parametrize("dims,fast", [((256, 16, 16, 128, 128, 4), 1), ((512, 32, 4, 256, 256, 4), 1),
                                        ((64, 16, 20, 128, 128, 4), 1), ((8, 4, 4, 32, 32, 4), 1), ((6, 5, 3, 24, 24, 4), 1),
                                        ((4, 3, 2, 16, 16, 2), 1), ((3, 2, 11, 64, 128, 4), 1), ((4, 2, 3, 32, 32, 8), 1),
                                        ((2, 2, 2, 10, 6, 2), 0), ((2, 2, 2, 9, 15, 3), 0), ((7, 3, 5, 6, 132, 2), 1),
                                        ((2, 3, 9, 24, 40, 8), 1), ((3, 2, 9, 32, 48, 16), 1), ((2, 2, 3, 64, 96, 32), 1),
-                                       ((2, 1, 2, 64, 128, 64), 1)])
+                                       ((2, 1, 2, 64, 128, 64), 1), ((3, 2, 5, 15, 120, 3), 1), ((2, 2, 3, 18, 36, 6), 1),
+                                       ((2, 2, 3, 34, 68, 17), 0), ((2, 2, 2, 27, 36, 9), 1), ((2, 2, 2, 20, 50, 5), 0),
+                                       ((256, 16, 16, 120, 120, 4), 1), ((3, 2, 5, 10, 36, 2), 1), ((2, 2, 9, 48, 80, 16), 1)])
 def test_planner_covers_geometry(dims, fast):
     """dfx_plan_make is host-only code: runs without a GPU."""
     from datafusion_amd import _cabi as cabi
@@ -166,12 +187,16 @@ def test_planner_covers_geometry(dims, fast):
     else:
         assert p.n_zchunks == 1 and p.cpb == 1 and 1 <= p.n_chunks <= n_t * n_l and p.n_blocks % p.n_chunks == 0
     assert p.u_part_elems == (p.n_chunks // max(p.cpb, 1)) * n_z * X * Y
-    row_parts = r // 4 if r in (16, 32, 64) else 1       # LaneMap<16>: the r / 4 waves of a block write a layer each
-    assert p.v_part_elems == p.n_zchunks * row_parts * n_t * n_l * (X // r) * (Y // r)
+    assert p.fast == _fast_expected(r, Y)
+    assert p.v_part_elems == p.n_zchunks * _v_layers_per_zchunk(r, X, Y) * n_t * n_l * (X // r) * (Y // r)
     assert p.part_elems >= max(p.n_blocks, cabi.EW_MAXBLOCKS) * cabi.NPART
     if fast:
-        if r in (16, 32, 64):
+        if r in (16, 32, 64) and Y % 32 == 0:
             wt = (X // r) * -(-Y // 64) * (r // 4)                        # bands x column groups of 64 x row parts
+        elif r not in (2, 4, 8) or Y % 32:
+            import math
+            cw = 64 // math.lcm(r, 4) * math.lcm(r, 4)                    # strip tile: 4 rows x cw columns
+            wt = -(-X // 4) * -(-Y // cw)
         else:
             wt = -(-(X // r) * (Y // r) // {2: 64, 4: 16, 8: 4}[r])      # wave tiles per plane: 64 / 16 / 4 blocks each
         assert p.cpb >= 1 and p.n_blocks == -(-wt // 4) * p.n_zchunks * -(-p.n_chunks // p.cpb)

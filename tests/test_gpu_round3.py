@@ -1,6 +1,7 @@
 """GPU tests added in round 3: the surface fixes the round-2 review asked for, the full-size meeting of the HIP path
 with the eager oracle (BASELINE configs[0] and [1]), bench.py's self-launch, and the rank-aware placement."""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -204,7 +205,7 @@ def test_solver_on_non_square_planes_vs_the_oracle(dims):
     xo = O.cg(O.prepare(spc, cmos, weights=w, init_type="random", tol=None), 6, with_loss=False)
     for residual in ("factored", "explicit"):
         f = FusionCG(spc, cmos, weights=w, init_type="random", tol=None, device=DEV, residual=residual)
-        assert f.k.plan.fast == (1 if Y % 4 == 0 and r in (2, 4, 8, 3, 5, 7, 16, 32, 64) else 0)
+        assert f.k.plan.fast == (1 if Y % 4 == 0 and math.lcm(r, 4) <= 64 else 0)
         x, _, _ = f(6, return_numpy=False)
         assert float(O.rel_l2(x.cpu(), xo)) <= TIGHT, (dims, residual)
 
