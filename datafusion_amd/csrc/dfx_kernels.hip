@@ -1451,7 +1451,8 @@ __device__ __forceinline__ float v_layers_sum(const float *v_part, const VLayers
     if (w.dense) {
         for (int c = 0; c < w.nzc * w.vq; ++c) s += v_part[(long long)c * w.vlen + i];
     } else {
-        const int xb = (int)(i % w.Ps) / w.Ys;
+        // 32-bit arithmetic whenever the small space allows it (a 64-bit modulo per block was most of this pass)
+        const int xb = (w.vlen <= 0x7fffffffLL ? (int)((unsigned)i % (unsigned)w.Ps) : (int)(i % w.Ps)) / w.Ys;
         const int s0 = (xb * w.r) >> 2, s1 = (xb * w.r + w.r - 1) >> 2;
         for (int z = 0; z < w.nzc; ++z)
             for (int t = s0; t <= s1; ++t) s += v_part[((long long)z * w.vq + t % w.vq) * w.vlen + i];
