@@ -48,6 +48,10 @@ WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "c2r16": (256, 16, 16, 128, 16),     # row-part tile (LaneMap<16>: r = 16, 32, 64)
     "c2r32": (256, 16, 16, 128, 32),
     "c2y120": (256, 16, 16, 120, 4),     # r = 4 on planes whose rows are not 128-byte aligned (480 B pitch)
+    "c2y100": (256, 16, 24, 100, 4),     # ... not 32-byte aligned either (Y % 8 != 0)
+    "c2y200": (128, 16, 13, 200, 4),
+    "c2r2y120": (256, 16, 16, 120, 2),
+    "c2r8y120": (256, 16, 16, 120, 8),
     "c2r3y96": (256, 16, 28, 96, 3),     # strip tile on 128-byte aligned rows (384 / 768 B pitch)
     "c2r3y192": (256, 16, 7, 192, 3),
     "c2gen": (256, 16, 16, 126, 3),      # Y % 4 != 0: the generic kernels (flat float4 sweep + the v pass)

@@ -87,6 +87,7 @@ struct Geo {
                    // (vq = the most strips a block row meets); 1 for the r = 2, 4, 8 maps and the generic kernels.
                    // v_part holds n_zchunks * vq layers of M * Ps floats; block row xb is the sum of the layers
                    // s % vq, s = floor(xb r / 4) .. floor((xb r + r - 1) / 4), of every z-chunk.
+    int lm;        // lane map of the fast kernels: 2, 4, 8 (LaneMap<R>), 16 (row-part tile), 1 (flat map), 0 (strip tile); -1: none
     int nblk;      // r x r blocks per plane = Xs*Ys
     int zs;        // planes per z-chunk of the plan in use (<= the kernel's ZC); set by the entry points
 };
@@ -142,40 +143,49 @@ int make_geo(const dfx_geom *g, Geo *o) {
     o->nblk = o->Xs * o->Ys;
     o->gL = o->gTPR = 0;
     o->vq = 1;
-    // the r = 2, 4, 8 and row-part maps stream with non-temporal accesses, which need plane rows that start on 128-byte
-    // lines (Y % 32 == 0): r = 4 on 120 x 120 planes ran at 0.34 of peak (every partial line fetched twice).  Other widths
-    // take the strip tile, whose accesses go through the L2.
-    const bool aligned_rows = (o->Y % 32) == 0 || getenv("DFX_NT_ANY_WIDTH") != nullptr;
-    if ((o->r == 2 || o->r == 4 || o->r == 8) && (aligned_rows || !general_lanes_per_row(o->r) || (o->Y % 4) != 0)) {
+    // the r = 2, 4, 8 and row-part maps stream 256 B row segments with non-temporal accesses, which need plane rows that
+    // start on 128-byte lines (Y % 32 == 0): r = 4 on 120 x 120 planes ran at 0.34 of peak (every partial line fetched
+    // twice).  On other widths a power-of-two r takes the flat map (lanes over the contiguous plane, one KiB per
+    // wave-instruction), every other r the strip tile, whose accesses go through the L2.
+    static const bool nt_any = getenv("DFX_NT_ANY_WIDTH") != nullptr, no_flat = getenv("DFX_NO_FLAT_MAP") != nullptr;
+    const bool aligned_rows = (o->Y % 32) == 0 || nt_any;
+    const bool pow2 = o->r == 2 || o->r == 4 || o->r == 8 || o->r == 16 || o->r == 32 || o->r == 64;
+    o->lm = -1;
+    o->WT = 0;
+    if ((o->Y % 4) != 0) {
+        // generic kernels
+    } else if ((o->r == 2 || o->r == 4 || o->r == 8) && aligned_rows) {
         const int bw = o->r == 2 ? 64 : (o->r == 8 ? 4 : 16);   // LaneMap<R>::BW
         o->WT = (o->nblk + bw - 1) / bw;
-    } else if (rowpart_tile(o->r) && (aligned_rows || !general_lanes_per_row(o->r))) {
+        o->lm = o->r;
+    } else if (rowpart_tile(o->r) && aligned_rows) {
         o->vq = o->r / 4;
         o->gTPR = (o->Y + 63) / 64;
         const long long wt = (long long)o->Xs * o->gTPR * o->vq;
         if (wt > 0x7fffffffLL) return fail(DFX_EINVAL, "plane too large");
         o->WT = (int)wt;
-    } else {
+        o->lm = 16;
+    } else if (pow2 && !no_flat && o->P / 4 <= 0x3fffffffLL) {
+        o->vq = o->r;                      // one layer of v_part per row of a block
+        o->WT = (int)((o->P / 4 + 63) / 64);
+        o->lm = 1;
+    } else if (general_lanes_per_row(o->r)) {
         o->gL = general_lanes_per_row(o->r);
-        if (o->gL && (o->Y % 4) == 0) {
-            o->gTPR = (o->Y + 4 * o->gL - 1) / (4 * o->gL);
-            const long long wt = (long long)((o->X + 3) / 4) * o->gTPR;
-            if (wt > 0x7fffffffLL) return fail(DFX_EINVAL, "plane too large");
-            o->WT = (int)wt;
-            o->vq = strip_layers(o->r, o->Xs);
-        } else {
-            o->gL = 0;
-            o->WT = 0;
-        }
+        o->gTPR = (o->Y + 4 * o->gL - 1) / (4 * o->gL);
+        const long long wt = (long long)((o->X + 3) / 4) * o->gTPR;
+        if (wt > 0x7fffffffLL) return fail(DFX_EINVAL, "plane too large");
+        o->WT = (int)wt;
+        o->vq = strip_layers(o->r, o->Xs);
+        o->lm = 0;
     }
     return 0;
 }
 
 // Y a multiple of 4 (every plane row 16-byte aligned) and r in {2, 4, 8} - a float4 never straddles a block row
 // (r = 4, 8) or covers exactly two blocks (r = 2), LaneMap<R> - or an r with a general tile (LaneMap<0>: 3, 5, 7, 16).
-bool fast_ok(const Geo &q) { return (q.r == 2 || q.r == 4 || q.r == 8 || q.gL > 0 || q.vq > 1) && (q.Y % 4) == 0; }
-// which lane map a fast plan uses: the r = 2, 4, 8 maps, the row-part tile (16) or the strip tile (0)
-int lane_map_of(const Geo &q) { return q.gL > 0 ? 0 : (q.vq > 1 ? 16 : q.r); }
+bool fast_ok(const Geo &q) { return q.lm >= 0; }
+// which lane map a fast plan uses: the r = 2, 4, 8 maps, the row-part tile (16), the flat map (1) or the strip tile (0)
+int lane_map_of(const Geo &q) { return q.lm; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -462,10 +472,56 @@ struct LaneMap<16> {
         return (f4){b, b, b, b};
     }
 };
+// Flat map (R = 1: r = 2, 4, 8, 16, 32, 64 on planes whose rows are not 128-byte aligned).  Lanes run over the plane as
+// it lies in memory - float4 f = 64 wt + lane - so every wave-instruction moves one contiguous KiB whatever Y is, and the
+// accesses can be non-temporal.  The rows of a block are then in different waves; nothing is exchanged: a float4 (r = 4),
+// r / 4 neighbouring lanes (r >= 8: r / 4 divides Y / 4, so the group never straddles a row or a wave) or each half of a
+// float4 (r = 2) is one ROW of a block, and row rho of every block goes to layer rho of v_part (Geo::vq = r dense layers,
+// added by the reducers like the z-chunks').
+template <>
+struct LaneMap<1> {
+    int blk, layer, r;
+    bool act, lead;
+    long long off2;
+    __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
+        r = q.r;
+        const int Y4 = q.Y >> 2;
+        const long long f = (long long)wt * 64 + lane;
+        act = wt < q.WT && f < (q.P >> 2);
+        const int fi = act ? (int)f : 0;
+        const int row = fi / Y4, j = fi - row * Y4;
+        off2 = 4LL * fi;
+        const int xb = row / r;
+        layer = row - xb * r;
+        blk = xb * q.Ys + (4 * j) / r;
+        lead = act && (r <= 4 || (4 * j) % r == 0);
+    }
+    __device__ __forceinline__ void vstore(f4 s4, float *vrow, int lane) const {
+        if (r == 2) {
+            *reinterpret_cast<float2 *>(vrow + blk) = make_float2(s4.x + s4.y, s4.z + s4.w);
+            return;
+        }
+        float s = hsum(s4);
+        if (r >= 8) s += __shfl_xor(s, 1);
+        if (r >= 16) s += __shfl_xor(s, 2);
+        if (r >= 32) s += __shfl_xor(s, 4);
+        if (r >= 64) s += __shfl_xor(s, 8);
+        if (lead) vrow[blk] = s;
+    }
+    __device__ __forceinline__ f4 bload(const float *brow) const {
+        if (r == 2) {
+            const float2 b = *reinterpret_cast<const float2 *>(brow + blk);
+            return (f4){b.x, b.x, b.y, b.y};
+        }
+        const float b = brow[blk];
+        return (f4){b, b, b, b};
+    }
+};
 // the layer of v_part a wave writes: its z-chunk, times the row parts of the row-part tile
 template <int R>
 __device__ __forceinline__ long long v_layer(const LaneMap<R> &L, const Geo &q) {
     if constexpr (R == 16) return (long long)blockIdx.y * q.vq + L.part;
+    else if constexpr (R == 1) return (long long)blockIdx.y * q.vq + L.layer;
     else if constexpr (R == 0) return (long long)blockIdx.y * q.vq + L.strip % q.vq;
     else return (long long)blockIdx.y;
 }
@@ -1463,7 +1519,7 @@ VLayers v_layers_of(const Geo &q, const dfx_plan *pl) {
     VLayers w;
     w.nzc = pl->n_zchunks;
     w.vq = q.vq;
-    w.dense = (q.vq == 1 || q.gL == 0) ? 1 : 0;   // strip tile: gL > 0
+    w.dense = q.lm != 0 ? 1 : 0;   // only the strip tile leaves layers unwritten
     w.r = q.r;
     w.Ys = q.Ys;
     w.Ps = q.Ps;
@@ -2210,6 +2266,7 @@ static int solo_lds_bytes() {
         else if ((lm) == 4) { constexpr int R_ = 4; __VA_ARGS__; }         \
         else if ((lm) == 8) { constexpr int R_ = 8; __VA_ARGS__; }         \
         else if ((lm) == 16) { constexpr int R_ = 16; __VA_ARGS__; }       \
+        else if ((lm) == 1) { constexpr int R_ = 1; __VA_ARGS__; }         \
         else { constexpr int R_ = 0; __VA_ARGS__; }                        \
     } while (0)
 #define DFX_DISPATCH_ZC_R(zc, r, ...)                                      \

@@ -148,7 +148,8 @@ def test_header_constants_match_python_mirror():
 
 
 def _v_layers_per_zchunk(r, X, Y):
-    """Layers of v_part per z-chunk (include/dfx.h, dfx_plan): r / 4 row parts for r = 16, 32, 64; for the strip tile
+    """Layers of v_part per z-chunk (include/dfx.h, dfx_plan): r / 4 row parts for r = 16, 32, 64; r for a power-of-two r
+    on planes whose rows are not 128-byte aligned (flat map); for the strip tile
     (any other r with lcm(r, 4) <= 64 and Y % 4 == 0 - and every r on planes whose rows are not 128-byte aligned, Y % 32 != 0)
     the most 4-row strips a block row meets; else 1."""
     import math
@@ -156,6 +157,8 @@ def _v_layers_per_zchunk(r, X, Y):
         return 1
     if r in (16, 32, 64) and Y % 32 == 0:
         return r // 4
+    if r in (2, 4, 8, 16, 32, 64):
+        return r                                        # flat map: a layer per row of a block
     if r < 2 or math.lcm(r, 4) > 64:
         return 1
     return max((xb * r + r - 1) // 4 - (xb * r) // 4 + 1 for xb in range(min(X // r, 4)))
@@ -193,6 +196,8 @@ def test_planner_covers_geometry(dims, fast):
     if fast:
         if r in (16, 32, 64) and Y % 32 == 0:
             wt = (X // r) * -(-Y // 64) * (r // 4)                        # bands x column groups of 64 x row parts
+        elif r in (2, 4, 8, 16, 32, 64):
+            wt = -(-(X * Y // 4) // 64)                                   # flat map: 64 float4 of the plane per wave
         elif r not in (2, 4, 8) or Y % 32:
             import math
             cw = 64 // math.lcm(r, 4) * math.lcm(r, 4)                    # strip tile: 4 rows x cw columns
