@@ -148,7 +148,8 @@ int make_geo(const dfx_geom *g, Geo *o) {
     // twice).  On other widths a power-of-two r takes the flat map (lanes over the contiguous plane, one KiB per
     // wave-instruction), every other r the strip tile, whose accesses go through the L2.
     static const bool nt_any = getenv("DFX_NT_ANY_WIDTH") != nullptr, no_flat = getenv("DFX_NO_FLAT_MAP") != nullptr;
-    const bool aligned_rows = (o->Y % 32) == 0 || nt_any;
+    static const bool flat_any = getenv("DFX_FLAT_ANY_WIDTH") != nullptr;   // measurement knob: flat map on aligned rows too
+    const bool aligned_rows = ((o->Y % 32) == 0 && !flat_any) || nt_any;
     const bool pow2 = o->r == 2 || o->r == 4 || o->r == 8 || o->r == 16 || o->r == 32 || o->r == 64;
     o->lm = -1;
     o->WT = 0;
