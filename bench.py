@@ -39,7 +39,7 @@ WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "cells": (64, 16, 20, 128, 4),       # README-like
     "c2r2": (256, 16, 16, 128, 2),       # C2 volume with spatial_increase 2 / 8 (LaneMap<2>, LaneMap<8>)
     "c2r8": (256, 16, 16, 128, 8),
-    "c2r3": (256, 16, 16, 120, 3),       # other block sizes: general tile (LaneMap<0>: r = 3, 5, 7 with Y % 4 == 0), else the generic kernels
+    "c2r3": (256, 16, 16, 120, 3),       # other block sizes: strip tile (LaneMap<0>: lcm(r, 4) <= 64 and Y % 4 == 0), else the generic kernels
     "c2r5": (256, 16, 16, 120, 5),
     "c2r6": (256, 16, 16, 120, 6),
     "c2r7": (256, 16, 16, 112, 7),

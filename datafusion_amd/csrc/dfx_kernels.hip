@@ -10,8 +10,10 @@
 //     cross-lane adds over the lanes holding the other rows of the block (r = 4: l^16, l^32);
 //   * the CG residual is never a 5-D array by default: r = ra[z,x,y] + rb[t,l,x/r,y/r] (k_resid_*).
 // No LDS tile and no barrier in the streaming loop; LDS is only used for the per-workgroup scalar partials.
-// r = 3, 5, 7, 16 run the same kernels over a general tile (LaneMap<0>: block sums through a wave-private LDS tile,
-// accesses through the L2); any other r, or Y % 4 != 0, takes the generic kernels (k_gen_sweep4 / k_gen_sweep2 + k_gen_proj_v2).
+// The same kernels run over four more lane maps (lane_map_of): a row-part tile for r = 16, 32, 64 (LaneMap<16>), and -
+// for planes whose rows are not 128-byte aligned, and for every other r up to 128 - lanes flat over the contiguous plane
+// (LaneMap<1>, LaneMap<3>), whose partial block sums go to layers of v_part.  Y % 4 != 0 takes the generic kernels
+// (k_gen_sweep4 / k_gen_sweep2 + k_gen_proj_v2).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -78,40 +80,16 @@ struct Geo {
     int M;         // nT*nL
     int nZ, X, Y, Xs, Ys, r;
     int WT;        // wave tiles per plane (fast path): ceil(nblk / BW), BW = 64, 16, 4 blocks per wave for r = 2, 4, 8;
-                   // general r (LaneMap<0>): Xs * gTPR
-    int gL;        // strip tile (LaneMap<0>, general r): lanes (float4) per tile row, 0 when r has no such tile; the tile is
-                   // 4 rows x 4 gL columns (a multiple of r and of 4)
-    int gTPR;      // strip tile: column groups per strip = ceil(Y / (4 gL)); row-part tile: column groups ceil(Y / 64)
-    int vq;        // layers of v_part per z-chunk.  Row-part tile (LaneMap<16>: r = 16, 32, 64): the r / 4 waves that share a
-                   // block write a layer each; strip tile: the 4-row strips that meet a block row write layer strip % vq
-                   // (vq = the most strips a block row meets); 1 for the r = 2, 4, 8 maps and the generic kernels.
-                   // v_part holds n_zchunks * vq layers of M * Ps floats; block row xb is the sum of the layers
-                   // s % vq, s = floor(xb r / 4) .. floor((xb r + r - 1) / 4), of every z-chunk.
-    int lm;        // lane map of the fast kernels: 2, 4, 8 (LaneMap<R>), 16 (row-part tile), 1 (flat map), 0 (strip tile); -1: none
+                   // row-part tile: 4-row strips x column groups; flat maps: ceil(X Y / 256)
+    int gTPR;      // row-part tile: column groups per strip = ceil(Y / 64)
+    int vq;        // layers of v_part per z-chunk, all dense (every layer holds every block; the reducers add them like
+                   // z-chunks): 1 for the r = 2, 4, 8 row maps and the generic kernels; r / 4 for the row-part tile (the
+                   // waves that share a block write a layer each); r for the flat map (a layer per row of a block); 2 r
+                   // for the flat map of other r (that, times two for runs a wave boundary cuts).
+    int lm;        // lane map of the fast kernels: 2, 4, 8 (row maps), 16 (row-part tile), 1 (flat map, power-of-two r), 3 (flat map, other r); -1: none
     int nblk;      // r x r blocks per plane = Xs*Ys
     int zs;        // planes per z-chunk of the plan in use (<= the kernel's ZC); set by the entry points
 };
-
-// Strip tile (LaneMap<0>, general r): a wave covers 4 rows x CW columns, CW = 4 L the largest multiple of lcm(r, 4) that
-// is <= 64 - whole blocks in y, whole float4s, 4 L of the 64 lanes at work (r = 3, 5, 6, 10, 12, 15, 20, 30: 60; 7, 14, 28:
-// 56; 13, 26: 52; 24, 48: 48; 11, 22, 44: 44; 9, 18, 36: 36).  0 sends the geometry to the generic kernels.
-int general_lanes_per_row(int r) {
-    static const bool off = getenv("DFX_NO_GENERAL_TILE") != nullptr;   // measurement knob: send every such r to the generic kernels
-    if (off || r < 2) return 0;
-    const int g = (r % 4 == 0) ? 4 : (r % 2 == 0 ? 2 : 1);
-    const int l = r / g * 4;            // lcm(r, 4)
-    if (l > 64) return 0;
-    return (64 / l) * l / 4;
-}
-// the most 4-row strips a block row of r rows meets
-int strip_layers(int r, int Xs) {
-    int most = 1;
-    for (int xb = 0; xb < Xs && xb < 4; ++xb) {
-        const int n = (xb * r + r - 1) / 4 - (xb * r) / 4 + 1;
-        if (n > most) most = n;
-    }
-    return most;
-}
 
 // Row-part tile (LaneMap<16>): r = 16, 32, 64 with the wave shape of r = 4 (4 rows x 64 columns, 256 B row segments);
 // a block's r rows are spread over r / 4 waves, which leave their partial block sums in layers of v_part.
@@ -141,13 +119,14 @@ int make_geo(const dfx_geom *g, Geo *o) {
     o->N = o->S * M;
     if (o->S > 0x7fffffffLL) return fail(DFX_EINVAL, "one (t,l) slab must stay below 2^31 elements");
     o->nblk = o->Xs * o->Ys;
-    o->gL = o->gTPR = 0;
+    o->gTPR = 0;
     o->vq = 1;
     // the r = 2, 4, 8 and row-part maps stream 256 B row segments with non-temporal accesses, which need plane rows that
     // start on 128-byte lines (Y % 32 == 0): r = 4 on 120 x 120 planes ran at 0.34 of peak (every partial line fetched
     // twice).  On other widths a power-of-two r takes the flat map (lanes over the contiguous plane, one KiB per
-    // wave-instruction), every other r the strip tile, whose accesses go through the L2.
+    // wave-instruction), and so does every other r (3 .. 128).
     static const bool nt_any = getenv("DFX_NT_ANY_WIDTH") != nullptr, no_flat = getenv("DFX_NO_FLAT_MAP") != nullptr;
+    static const bool no_general = getenv("DFX_NO_GENERAL_TILE") != nullptr;   // measurement knob: other r -> generic kernels
     static const bool flat_any = getenv("DFX_FLAT_ANY_WIDTH") != nullptr;   // measurement knob: flat map on aligned rows too
     const bool aligned_rows = ((o->Y % 32) == 0 && !flat_any) || nt_any;
     const bool pow2 = o->r == 2 || o->r == 4 || o->r == 8 || o->r == 16 || o->r == 32 || o->r == 64;
@@ -170,22 +149,17 @@ int make_geo(const dfx_geom *g, Geo *o) {
         o->vq = o->r;                      // one layer of v_part per row of a block
         o->WT = (int)((o->P / 4 + 63) / 64);
         o->lm = 1;
-    } else if (general_lanes_per_row(o->r)) {
-        o->gL = general_lanes_per_row(o->r);
-        o->gTPR = (o->Y + 4 * o->gL - 1) / (4 * o->gL);
-        const long long wt = (long long)((o->X + 3) / 4) * o->gTPR;
-        if (wt > 0x7fffffffLL) return fail(DFX_EINVAL, "plane too large");
-        o->WT = (int)wt;
-        o->vq = strip_layers(o->r, o->Xs);
-        o->lm = 0;
+    } else if (o->r >= 3 && o->r <= 128 && !no_general && o->P / 4 <= 0x3fffffffLL) {
+        o->vq = 2 * o->r;                  // a layer per row of a block, times two: the part a wave boundary cuts off
+        o->WT = (int)((o->P / 4 + 63) / 64);
+        o->lm = 3;
     }
     return 0;
 }
 
-// Y a multiple of 4 (every plane row 16-byte aligned) and r in {2, 4, 8} - a float4 never straddles a block row
-// (r = 4, 8) or covers exactly two blocks (r = 2), LaneMap<R> - or an r with a general tile (LaneMap<0>: 3, 5, 7, 16).
+// Y a multiple of 4 (every plane row 16-byte aligned) and 2 <= r <= 128: one of the lane maps make_geo chose
 bool fast_ok(const Geo &q) { return q.lm >= 0; }
-// which lane map a fast plan uses: the r = 2, 4, 8 maps, the row-part tile (16), the flat map (1) or the strip tile (0)
+// which lane map a fast plan uses: the r = 2, 4, 8 row maps, the row-part tile (16), the flat maps (1, 3)
 int lane_map_of(const Geo &q) { return q.lm; }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -262,33 +236,10 @@ __device__ __forceinline__ void st4s(float *p, f4 v) {
     st4(p, v);
 #endif
 }
-// the lane-mapped kernels pick the policy per lane map: the r = 2, 4, 8 tiles read and write whole 128 / 256 / 512 B row
-// segments and stream them non-temporally; the general-r tile (LaneMap<0>) has row segments of 48 - 336 B that do not end
-// on sector boundaries, and non-temporal stores of partial sectors cost it 1.5 - 2.7x (measured at C2 size, r = 3 / 6 /
-// 12 / 16: 5.58 / 8.01 / 13.67 / 4.85 ms non-temporal against 3.67 / 3.82 / 5.02 / 3.22 ms through the L2; non-temporal loads
-// with cached stores: 4.59 / 5.06 / 8.15 / 5.63 ms).  What did NOT matter: the LDS block sums (same times without them),
-// and handing each XCD a contiguous range of tile groups so that shared lines meet in one L2 (+-1 %).
-#ifndef DFX_GEN_ZB
-#define DFX_GEN_ZB 4      // DFX_ZB of the general tile (LaneMap<0>)
-#endif
-#ifndef DFX_GEN_NT_LD
-#define DFX_GEN_NT_LD 0
-#endif
-#ifndef DFX_GEN_NT_ST
-#define DFX_GEN_NT_ST 0
-#endif
-template <bool NT>
-__device__ __forceinline__ f4 ld4t(const float *p) { return NT ? ld4s(p) : ld4(p); }
-template <bool NT>
-__device__ __forceinline__ void st4t(float *p, f4 v) {
-    if (NT) st4s(p, v);
-    else st4(p, v);
-}
-template <int R>
-struct Stream {
-    static constexpr bool LD = R == 0 ? (DFX_GEN_NT_LD != 0) : true;   // true: as DFX_NT says
-    static constexpr bool ST = R == 0 ? (DFX_GEN_NT_ST != 0) : true;
-};
+// Every lane map streams the 5-D vectors non-temporally (ld4s / st4s).  That needs wave accesses that start and end on
+// 128-byte lines - the row maps on planes with Y % 32 == 0, the flat maps anywhere: a tile with row segments of 48 - 336 B
+// (this round's first general-r tile) ran 1.5 - 2.7x slower non-temporally than through the L2, and r = 4's row map on
+// 120-wide planes at 0.34 of peak.
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float dot4(f4 a, f4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
@@ -346,92 +297,6 @@ struct LaneMap {
     }
 };
 
-// Strip tile (R = 0: general r, see general_lanes_per_row).  The wave keeps the shape of r = 4 - 4 rows x CW <= 64
-// columns, wave tiles numbered column groups first, then the 4-row strips of the plane, so that a workgroup touches one
-// contiguous run of rows - whatever r is.  A strip meets one or two block rows (r >= 3) and a float4 one or two blocks,
-// so the block sums go through a wave-private LDS tile instead of shuffles: every lane stores its z-summed float4; the
-// lanes of the strip's first row add, for their four columns, the rows that lie in the upper and in the lower block row;
-// then the active lanes share out the (up to 2 x CW / r) blocks and add r column sums each.  The partial block sums
-// of a strip go to layer strip % vq of v_part (Geo::vq).  LDS operations of one wave execute in order; the wavefront-
-// scope fences keep the compiler from moving them across each other.  Everything else (u accumulators, ra in
-// registers, 16 B accesses) is the fast path's.  (Round 3's first general tile was r rows x 4 L columns with r L <= 64:
-// short row segments, a ragged last tile per band; r = 3 / 5 / 7 ran at 0.55 of peak.)
-template <>
-struct LaneMap<0> {
-    bool act;
-    long long off2;   // element offset of the lane's float4 inside a plane
-    int bi;           // small-space index (inside a plane of Xs x Ys) of the block under the float4's first element
-    int cut;          // how many of the four elements lie in that block (the rest in block bi + 1); >= 4: all
-    int lds;          // this lane's float4 in the wave's LDS tile (floats)
-    int r, strip;
-    int nrows, k;     // live rows of the strip (4, fewer at the bottom of the plane); rows of them in the upper block row
-    int csum;         // >= 0: this lane adds the rows of columns [csum, csum + 4) of the tile
-    int ord, nact;    // ordinal of this lane among the wave's active lanes, and their number
-    int nbc, ncell;   // blocks per block row in this column group; blocks the strip contributes to (nbc or 2 nbc)
-    int vb0;          // small-space index of the strip's first block (upper block row, this column group)
-    int Ys;
-    __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
-        const int L = q.gL, CW = 4 * L;
-        r = q.r;
-        Ys = q.Ys;
-        strip = wt / q.gTPR;
-        const int cg = wt - strip * q.gTPR;
-        const int dx = lane / L, j = lane - dx * L;
-        const int R0 = 4 * strip, row = R0 + dx, col = cg * CW + 4 * j;
-        const bool live = wt < q.WT;
-        act = live && dx < 4 && row < q.X && col < q.Y;
-        off2 = (long long)row * q.Y + col;
-        const int xb = row / r, yb = col / r;
-        bi = xb * q.Ys + yb;
-        cut = r - (col - yb * r);
-        lds = dx * 64 + 4 * j;
-        const int A = R0 / r;
-        nrows = min(4, q.X - R0);
-        k = min(nrows, (A + 1) * r - R0);
-        const int yt = live ? min(CW, q.Y - cg * CW) : 0;   // live columns of this group: a multiple of 4 and of r
-        const int apr = yt >> 2;                               // active lanes per row
-        nbc = yt / r;
-        ncell = (k < nrows) ? 2 * nbc : nbc;
-        csum = (act && dx == 0) ? 4 * j : -1;
-        ord = dx * apr + j;
-        nact = nrows * apr;
-        vb0 = A * q.Ys + (cg * CW) / r;
-    }
-    __device__ __forceinline__ void vstore(f4 s4, float *vrow, int lane) const {
-        __shared__ __attribute__((aligned(16))) float tile[DFX_WAVES][6 * 64];   // 4 rows x 64 floats + 2 rows of column sums
-        float *t = tile[threadIdx.x >> 6];
-        float *cs = t + 4 * 64;
-        *reinterpret_cast<f4 *>(t + lds) = s4;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (csum >= 0) {
-            f4 up = *reinterpret_cast<const f4 *>(t + csum), lo = {0.f, 0.f, 0.f, 0.f};
-            for (int d = 1; d < k; ++d) up += *reinterpret_cast<const f4 *>(t + d * 64 + csum);
-            for (int d = k; d < nrows; ++d) lo += *reinterpret_cast<const f4 *>(t + d * 64 + csum);
-            *reinterpret_cast<f4 *>(cs + csum) = up;
-            *reinterpret_cast<f4 *>(cs + 64 + csum) = lo;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int c = ord; c < ncell; c += nact) {
-            const int half = c >= nbc ? 1 : 0, cb = c - half * nbc;
-            const float *src = cs + half * 64 + cb * r;
-            float sum = src[0];
-            for (int d = 1; d < r; ++d) sum += src[d];
-            vrow[vb0 + half * Ys + cb] = sum;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next slab's stores stay behind these reads
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ f4 bload(const float *brow) const {
-        const float b0 = brow[bi];
-        const float b1 = cut < 4 ? brow[bi + 1] : b0;
-        return (f4){b0, cut > 1 ? b0 : b1, cut > 2 ? b0 : b1, cut > 3 ? b0 : b1};
-    }
-};
-
 // Row-part tile (R = 16: r = 16, 32, 64).  The wave has the shape of r = 4 - 4 rows x 16 float4, 256 B per row segment -
 // and covers a 4-row strip of 64 / r blocks; wave tiles are numbered like r = 4's (column groups, then strips).  A wave adds its 4 rows x r columns per block with shuffles and
 // stores the partial in ITS layer of v_part (layer = z-chunk * r/4 + row part); the layers are added where the
@@ -447,7 +312,7 @@ struct LaneMap<16> {
     __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
         r = q.r;
         // wave tiles in the order of r = 4: column groups fastest, then the 4-row strips of the plane - a workgroup's four
-        // waves touch one contiguous run of rows (2.80 -> ? ms at C2 size against strips of one block first)
+        // waves touch one contiguous run of rows (2.69 ms at C2 size with r = 16 against 2.80 with the strips of one block first)
         const int strip = wt / q.gTPR, cg = wt - strip * q.gTPR;
         const int xb = strip / q.vq;
         part = strip - xb * q.vq;
@@ -518,12 +383,88 @@ struct LaneMap<1> {
         return (f4){b, b, b, b};
     }
 };
+// Flat map for any other r (R = 3: 3 <= r <= 128).  Lanes over the plane as it lies in memory, like LaneMap<1>; here a
+// float4 can straddle two blocks and a block's columns need not start at a lane, a row or a wave.  Per row, the lanes'
+// values form a sequence a_0 b_0 a_1 b_1 ... (a: the float4's elements in its first block, b: those in the next) in
+// which every block row is a run; the run's first element - its "head" - adds the a's of the lanes behind it (wave-
+// private LDS: one ds_write_b32 per lane, the heads read <= r / 4 + 1 values) and stores the sum in layer 2 rho of
+// v_part, rho = the row inside the block.  A run that a wave boundary cuts in two leaves its second part in layer
+// 2 rho + 1 (written by lane 0 of the next wave); every other head writes a zero there, so that all 2 r layers are
+// dense and the reducers add them like z-chunks.  Nothing else is exchanged between lanes.
+template <>
+struct LaneMap<3> {
+    bool act;
+    long long off2;
+    int bi, cut;          // block under the float4's first element; how many of the four elements lie in it (>= 4: all)
+    int a_n, b_n;         // lanes whose a this lane adds as head of its first / second block's run (0: not a head); the
+                          // a-run includes the lane itself, the b-run starts with its own b and adds the a of b_n - 1 lanes behind
+    int a_sub;            // 1: the a-run continues a block row cut by the wave boundary (layer 2 rho + 1)
+    bool a_zero, b_zero;  // the run ends inside this wave: write the zero of layer 2 rho + 1
+    int layer;            // 2 rho
+    long long lstride;    // floats between two layers
+    __device__ __forceinline__ LaneMap(const Geo &q, int wt, int lane) {
+        const int r = q.r, Y4 = q.Y >> 2;
+        const long long f = (long long)wt * 64 + lane, F = q.P >> 2;
+        act = wt < q.WT && f < F;
+        const int fi = act ? (int)f : 0;
+        const int row = fi / Y4, j = fi - row * Y4, col = 4 * j;
+        off2 = 4LL * fi;
+        const int xb = row / r, ca = col / r;
+        layer = 2 * (row - xb * r);
+        lstride = (long long)q.M * q.Ps;
+        bi = xb * q.Ys + ca;
+        cut = r - (col - ca * r);
+        // lanes of this wave behind this one that are live and in the same row
+        const long long wave_end = min((long long)wt * 64 + 64, F);
+        const int behind = (int)min((long long)(Y4 - 1 - j), wave_end - 1 - f);
+        // first block: head when the block starts at this float4, at the start of the row or at the start of the wave
+        const bool a_head = act && (lane == 0 || j == 0 || col - ca * r == 0);
+        const int a_last = (ca * r + r - 1) >> 2;                  // float4 (within the row) holding the block's last column
+        a_n = a_head ? min(a_last - j, behind) + 1 : 0;
+        a_sub = (a_head && lane == 0 && j != 0 && col - ca * r != 0) ? 1 : 0;
+        a_zero = a_head && !a_sub && (a_last - j <= behind);
+        // second block: always a head when the float4 reaches into it
+        const bool b_head = act && cut < 4;
+        const int b_last = ((ca + 1) * r + r - 1) >> 2;
+        b_n = b_head ? min(b_last - j, behind) + 1 : 0;
+        b_zero = b_head && (b_last - j <= behind);
+    }
+    __device__ __forceinline__ void vstore(f4 s4, float *vrow, int lane) const {
+        __shared__ float runs[DFX_WAVES][64];
+        float *t = runs[threadIdx.x >> 6];
+        const float e0 = s4.x, e1 = s4.y, e2 = s4.z, e3 = s4.w;
+        const float a = cut >= 4 ? (e0 + e1) + (e2 + e3) : (cut == 3 ? (e0 + e1) + e2 : (cut == 2 ? e0 + e1 : e0));
+        const float b = cut >= 4 ? 0.f : (cut == 3 ? e3 : (cut == 2 ? e2 + e3 : (e1 + e2) + e3));
+        t[lane] = a;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (a_n) {
+            float sum = a;
+            for (int k = 1; k < a_n; ++k) sum += t[lane + k];
+            vrow[(long long)a_sub * lstride + bi] = sum;
+            if (a_zero) vrow[lstride + bi] = 0.f;
+        }
+        if (b_n) {
+            float sum = b;
+            for (int k = 1; k < b_n; ++k) sum += t[lane + k];
+            vrow[bi + 1] = sum;
+            if (b_zero) vrow[lstride + bi + 1] = 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next slab's store stays behind these reads
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ f4 bload(const float *brow) const {
+        const float b0 = brow[bi];
+        const float b1 = cut < 4 ? brow[bi + 1] : b0;
+        return (f4){b0, cut > 1 ? b0 : b1, cut > 2 ? b0 : b1, cut > 3 ? b0 : b1};
+    }
+};
 // the layer of v_part a wave writes: its z-chunk, times the row parts of the row-part tile
 template <int R>
 __device__ __forceinline__ long long v_layer(const LaneMap<R> &L, const Geo &q) {
     if constexpr (R == 16) return (long long)blockIdx.y * q.vq + L.part;
-    else if constexpr (R == 1) return (long long)blockIdx.y * q.vq + L.layer;
-    else if constexpr (R == 0) return (long long)blockIdx.y * q.vq + L.strip % q.vq;
+    else if constexpr (R == 1 || R == 3) return (long long)blockIdx.y * q.vq + L.layer;
     else return (long long)blockIdx.y;
 }
 
@@ -559,9 +500,7 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
     // the ZN live planes go in groups of DFX_ZB (loads issued together, then updated and stored); the LAST group takes
     // the remainder too (ZN = 5 -> 2 + 3, 7 -> 2 + 2 + 3), so that no group runs with fewer loads in flight than the
     // others (5 as 2 + 2 + 1 cost three group latencies for five planes: 87 % of the per-plane rate of 4 or 8)
-    // the general tile leaves lanes idle (36 - 63 of 64): four planes per group keep as many loads in flight (measured at
-    // C2 size, r = 3 / 6 / 7 / 12 / 16: 3.39 / 3.73 / 2.95 / 4.52 / 3.15 ms against 3.67 / 3.82 / 3.03 / 5.02 / 3.22 with two)
-    constexpr int ZB = R == 0 ? DFX_GEN_ZB : DFX_ZB;
+    constexpr int ZB = DFX_ZB;
     constexpr int NG = (ZN / ZB) > 0 ? ZN / ZB : 1;
     constexpr int GS = (2 * ZB - 1) < ZN ? (2 * ZB - 1) : ZN;     // largest group
     for (int m = m0; m < m1; m += ms) {
@@ -580,17 +519,17 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
                 if (j < cnt) {
                     const long long i = base + (long long)(g + j) * a.q.P;
                     if (MODE == DFX_SWEEP_PROJECT) {
-                        xv[j] = ld4t<Stream<R>::LD>(a.x + i);
+                        xv[j] = ld4s(a.x + i);
                     } else if (MODE == DFX_SWEEP_XP) {
-                        xv[j] = ld4t<Stream<R>::LD>(a.x + i);
-                        rv[j] = FACT ? rav[g + j] + rb4 : ld4t<Stream<R>::LD>(a.r + i);
-                        pv[j] = ld4t<Stream<R>::LD>(a.p + i);
+                        xv[j] = ld4s(a.x + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
+                        pv[j] = ld4s(a.p + i);
                     } else if (MODE == DFX_SWEEP_P) {
-                        rv[j] = FACT ? rav[g + j] + rb4 : ld4t<Stream<R>::LD>(a.r + i);
-                        pv[j] = ld4t<Stream<R>::LD>(a.p + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
+                        pv[j] = ld4s(a.p + i);
                     } else {  // PINIT
-                        xv[j] = ld4t<Stream<R>::LD>(a.x + i);
-                        rv[j] = FACT ? rav[g + j] + rb4 : ld4t<Stream<R>::LD>(a.r + i);
+                        xv[j] = ld4s(a.x + i);
+                        rv[j] = FACT ? rav[g + j] + rb4 : ld4s(a.r + i);
                     }
                 }
             }
@@ -605,18 +544,18 @@ __device__ __forceinline__ void sweep_steps(const SweepArgs &a, int m0, int m1, 
                     } else if (MODE == DFX_SWEEP_XP) {
                         const f4 xn = xv[j] + fa * pv[j];
                         pn = rv[j] + fb * pv[j];
-                        st4t<Stream<R>::ST>(a.x + i, xn);
-                        st4t<Stream<R>::ST>(a.p + i, pn);
+                        st4s(a.x + i, xn);
+                        st4s(a.p + i, pn);
                         xx += dot4(xn, xn);
                         xp += dot4(xn, pn);
                         pp += dot4(pn, pn);
                     } else if (MODE == DFX_SWEEP_P) {
                         pn = rv[j] + fb * pv[j];
-                        st4t<Stream<R>::ST>(a.p + i, pn);
+                        st4s(a.p + i, pn);
                         pp += dot4(pn, pn);
                     } else {
                         pn = rv[j];
-                        st4t<Stream<R>::ST>(a.p + i, pn);
+                        st4s(a.p + i, pn);
                         xx += dot4(xv[j], xv[j]);
                         xp += dot4(xv[j], pn);
                         pp += dot4(pn, pn);
@@ -725,7 +664,7 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int m0, int m1, 
                 if (HAS_IN) {
                     const long long base = (long long)mm * a.q.S + off;
 #pragma unroll
-                    for (int k = 0; k < ZN; ++k) iv[u][k] = ld4t<Stream<R>::LD>(a.in + base + (long long)k * a.q.P);
+                    for (int k = 0; k < ZN; ++k) iv[u][k] = ld4s(a.in + base + (long long)k * a.q.P);
                 }
             }
         }
@@ -740,7 +679,7 @@ __device__ __forceinline__ void bcast_steps(const BcastArgs &a, int m0, int m1, 
                     {
                         f4 o = av[k] + (HAS_MASK ? mk[k] * b[u] : b[u]);
                         if (HAS_IN) o += iv[u][k];
-                        st4t<Stream<R>::ST>(a.out + base + (long long)k * a.q.P, o);
+                        st4s(a.out + base + (long long)k * a.q.P, o);
                         rr += dot4(o, o);
                     }
                 }
@@ -899,10 +838,10 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
             for (int j = 0; j < GS; ++j) {
                 if (j < cnt) {
                     const long long i = base + (long long)(g + j) * a.q.P;
-                    xv[j] = ld4t<Stream<R>::LD>(a.x + i);
-                    if (GRAD) gv[j] = ld4t<Stream<R>::LD>(a.grad + i);
-                    if (!M1F) e1[j] = ld4t<Stream<R>::LD>(a.m1 + i);
-                    e2[j] = ld4t<Stream<R>::LD>(a.m2 + i);
+                    xv[j] = ld4s(a.x + i);
+                    if (GRAD) gv[j] = ld4s(a.grad + i);
+                    if (!M1F) e1[j] = ld4s(a.m1 + i);
+                    e2[j] = ld4s(a.m2 + i);
                 }
             }
 #pragma unroll
@@ -919,9 +858,9 @@ __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const LaneMap<R> &
                     // GRAD: DfxAdam's step - torch's arithmetic bit for bit (IEEE sqrt and division), like k_adam_apply
                     const f4 xn = GRAD ? adam_elem4<false, false>(xv[j], gr, e1[j], e2[j], a)
                                        : adam_elem4<M1F>(xv[j], gr, e1[j], e2[j], a);
-                    st4t<Stream<R>::ST>(a.x + i, xn);
-                    if (!M1F) st4t<Stream<R>::ST>(a.m1 + i, e1[j]);
-                    st4t<Stream<R>::ST>(a.m2 + i, e2[j]);
+                    st4s(a.x + i, xn);
+                    if (!M1F) st4s(a.m1 + i, e1[j]);
+                    st4s(a.m2 + i, e2[j]);
                     const f4 d = xn - xv[j];
                     dd += dot4(d, d);
                     xx += dot4(xn, xn);
@@ -1497,41 +1436,15 @@ __global__ __launch_bounds__(256) void k_reduce_u(const float *u_part, float *u,
     block_store3(acc, 0.0, 0.0, part + (long long)blockIdx.x * DFX_NPART);
 }
 
-// The layers of v_part (Geo::vq).  dense: every layer holds every block (z-chunks; the row parts of LaneMap<16>);
-// otherwise (strip tile) block row xb is in the layers s % vq of the strips s that meet it.
-struct VLayers {
-    int nzc, vq, dense, r, Ys;
-    long long Ps, vlen;
-};
-__device__ __forceinline__ float v_layers_sum(const float *v_part, const VLayers &w, long long i) {
-    float s = 0.f;
-    if (w.dense) {
-        for (int c = 0; c < w.nzc * w.vq; ++c) s += v_part[(long long)c * w.vlen + i];
-    } else {
-        // 32-bit arithmetic whenever the small space allows it (a 64-bit modulo per block was most of this pass)
-        const int xb = (w.vlen <= 0x7fffffffLL ? (int)((unsigned)i % (unsigned)w.Ps) : (int)(i % w.Ps)) / w.Ys;
-        const int s0 = (xb * w.r) >> 2, s1 = (xb * w.r + w.r - 1) >> 2;
-        for (int z = 0; z < w.nzc; ++z)
-            for (int t = s0; t <= s1; ++t) s += v_part[((long long)z * w.vq + t % w.vq) * w.vlen + i];
-    }
-    return s;
-}
-VLayers v_layers_of(const Geo &q, const dfx_plan *pl) {
-    VLayers w;
-    w.nzc = pl->n_zchunks;
-    w.vq = q.vq;
-    w.dense = q.lm != 0 ? 1 : 0;   // only the strip tile leaves layers unwritten
-    w.r = q.r;
-    w.Ys = q.Ys;
-    w.Ps = q.Ps;
-    w.vlen = (long long)q.M * q.Ps;
-    return w;
-}
-
-__global__ __launch_bounds__(256) void k_reduce_v(const float *v_part, float *v, long long lo, long long hi, VLayers w) {
+// v = the sum of the layers of v_part (z-chunks x Geo::vq), slabs [lo, hi)
+__global__ __launch_bounds__(256) void k_reduce_v(const float *v_part, float *v, long long lo, long long hi,
+                                                  long long len, int n_layers) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride)
-        v[i] = v_layers_sum(v_part, w, i);
+    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
+        float s = 0.f;
+        for (int c = 0; c < n_layers; ++c) s += v_part[(long long)c * len + i];
+        v[i] = s;
+    }
 }
 
 // mode 0: sum a^2 ; 1: sum mask*(a-b)^2 ; 2: sum a
@@ -1611,7 +1524,6 @@ struct PostArgs {
     long long S, vlen;
     int n_urows, n_zchunks, nbu, nbv, n_fold_rows, flags;   // n_zchunks: layers of v_part (z-chunks x Geo::vq)
     double c1, c2, eps;
-    VLayers vl;
 };
 
 __global__ __launch_bounds__(256) void k_post_sweep(const PostArgs a) {
@@ -1641,7 +1553,7 @@ __global__ __launch_bounds__(256) void k_post_sweep(const PostArgs a) {
     } else if (a.flags & DFX_POST_V) {
         const long long stride = (long long)a.nbv * 256;
         const long long t0 = (long long)(b - a.nbu) * 256 + threadIdx.x;
-        const bool vec = (a.vlen % 4 == 0) && ((((uintptr_t)a.v_part | (uintptr_t)a.v) & 15) == 0) && (a.vl.dense || !a.v);
+        const bool vec = (a.vlen % 4 == 0) && ((((uintptr_t)a.v_part | (uintptr_t)a.v) & 15) == 0);
         if (vec) {
             for (long long i = t0; i < a.vlen / 4; i += stride) {
                 f4 sacc = ld4(a.v_part + 4 * i);
@@ -1653,12 +1565,10 @@ __global__ __launch_bounds__(256) void k_post_sweep(const PostArgs a) {
             }
         } else {
             for (long long i = t0; i < a.vlen; i += stride) {
-                float sacc;
+                float sacc = a.v_part[i];
                 if (a.v) {
-                    sacc = v_layers_sum(a.v_part, a.vl, i);
+                    for (int c = 1; c < a.n_zchunks; ++c) sacc += a.v_part[(long long)c * a.vlen + i];
                     a.v[i] = sacc;
-                } else {
-                    sacc = a.v_part[i];
                 }
                 vv += (double)sacc * (double)sacc;
             }
@@ -2259,7 +2169,7 @@ static int solo_lds_bytes() {
         hipLaunchKernelGGL(kfn_, grid, block, dyn_, st, __VA_ARGS__);                                                \
     } while (0)
 
-// the fast kernels exist for zc in {4, 8} x r in {2, 4, 8, row-part tile (LaneMap<16>), general (LaneMap<0>)}; check_plan / fast_ok admit nothing else
+// the fast kernels exist for zc in {4, 8} x lane map in {2, 4, 8, 16 (row-part tile), 1, 3 (flat maps)}; check_plan / fast_ok admit nothing else
 #define DFX_DISPATCH_R(ZCV, lm, ...)                                       \
     do {                                                                   \
         constexpr int ZC_ = ZCV;                                           \
@@ -2268,7 +2178,7 @@ static int solo_lds_bytes() {
         else if ((lm) == 8) { constexpr int R_ = 8; __VA_ARGS__; }         \
         else if ((lm) == 16) { constexpr int R_ = 16; __VA_ARGS__; }       \
         else if ((lm) == 1) { constexpr int R_ = 1; __VA_ARGS__; }         \
-        else { constexpr int R_ = 0; __VA_ARGS__; }                        \
+        else { constexpr int R_ = 3; __VA_ARGS__; }                        \
     } while (0)
 #define DFX_DISPATCH_ZC_R(zc, r, ...)                                      \
     do {                                                                   \
@@ -2855,7 +2765,6 @@ int dfx_post_sweep(const dfx_geom *g, const dfx_plan *pl, const float *u_part, f
     a.vlen = (long long)q.M * q.Ps;
     a.n_urows = pl->n_chunks / pl->cpb;
     a.n_zchunks = v_layers;
-    a.vl = v_layers_of(q, pl);
     a.nbu = 0;
     a.nbv = 0;
     if (flags & DFX_POST_U) {
@@ -2903,7 +2812,7 @@ int dfx_reduce_v(const dfx_geom *g, const dfx_plan *pl, const float *v_part, flo
     if (!v_part || !v) return fail(DFX_EINVAL, "dfx_reduce_v: NULL buffer");
     if (m_lo < 0 || m_hi > q.M || m_lo >= m_hi) return fail(DFX_EINVAL, "dfx_reduce_v: bad slab range");
     hipLaunchKernelGGL(k_reduce_v, dim3(ew_blocks((m_hi - m_lo) * q.Ps, 1)), dim3(256), 0, (hipStream_t)stream, v_part,
-                       v, (long long)m_lo * q.Ps, (long long)m_hi * q.Ps, v_layers_of(q, pl));
+                       v, (long long)m_lo * q.Ps, (long long)m_hi * q.Ps, (long long)q.M * q.Ps, pl->n_zchunks * q.vq);
     DFX_LAUNCH_CHECK("dfx_reduce_v");
     return 0;
 }

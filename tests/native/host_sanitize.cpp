@@ -12,12 +12,8 @@ static int layers_per_zchunk(int r, int Xs, long long Y) {
     if ((r == 2 || r == 4 || r == 8) && Y % 32 == 0) return 1;
     if ((r == 16 || r == 32 || r == 64) && Y % 32 == 0) return r / 4;
     if (r == 2 || r == 4 || r == 8 || r == 16 || r == 32 || r == 64) return r;   // flat map
-    int most = 1;
-    for (int xb = 0; xb < Xs && xb < 4; ++xb) {
-        const int n = (xb * r + r - 1) / 4 - (xb * r) / 4 + 1;
-        if (n > most) most = n;
-    }
-    return most;
+    (void)Xs;
+    return (r >= 3 && r <= 128) ? 2 * r : 1;   // flat map for any r
 }
 
 int main() {

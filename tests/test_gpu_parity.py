@@ -272,7 +272,7 @@ def test_sliced_sweep_is_bitwise_identical():
                                   (2, 2, 3, 12, 20, 2), (3, 1, 2, 16, 24, 8), (2, 2, 2, 9, 15, 3), (2, 2, 2, 10, 6, 2),
                                   (7, 3, 5, 6, 132, 2), (2, 3, 9, 24, 40, 8), (5, 3, 7, 64, 128, 2), (5, 3, 7, 64, 128, 8),
                                   (70, 2, 4, 2, 4, 2), (3, 2, 3, 8, 8, 8),
-                                  # general block sizes (LaneMap<0>): one tile, ragged last tile in y, several bands, the
+                                  # other block sizes (flat map for any r, LaneMap<3>): one wave, several rows per wave, several waves per row, the
                                   # widest tiles, lanes of three tile rows summing blocks (r = 3), a one-block wave (r = 16)
                                   (2, 2, 2, 9, 12, 3), (3, 2, 5, 12, 96, 3), (2, 3, 9, 15, 180, 3), (2, 2, 3, 10, 60, 5),
                                   (3, 1, 7, 18, 48, 6), (2, 2, 4, 14, 56, 7), (2, 1, 3, 20, 40, 10), (2, 2, 5, 24, 36, 12),
@@ -282,16 +282,20 @@ def test_sliced_sweep_is_bitwise_identical():
                                   # with an odd number of column groups), a block wider than... the 64-column group (r = 64)
                                   (2, 2, 3, 16, 16, 16), (3, 2, 17, 48, 208, 16), (2, 3, 5, 64, 96, 32), (3, 1, 4, 32, 160, 32),
                                   (2, 2, 9, 64, 64, 64), (1, 3, 2, 128, 192, 64), (67, 2, 4, 16, 144, 16),
-                                  # strip tile (LaneMap<0>): a last strip of 1, 2, 3 rows, one block per strip (r = 3 on a
-                                  # 1-row strip: more blocks than active lanes), 36 of 64 lanes (r = 9), r = 12, 20, 28, several
-                                  # column groups with a ragged last one, two z-chunks x strip layers
+                                  # more of the same (shapes that exercised the strip tile this map replaced): rows of 3 - 35
+                                  # float4, planes that end inside a wave, r = 9, 12, 20, 28, two z-chunks x 2 r layers
                                   (2, 2, 3, 9, 24, 3), (3, 2, 2, 21, 132, 3), (2, 2, 5, 15, 60, 5), (2, 3, 17, 30, 140, 10),
                                   (2, 2, 3, 27, 72, 9), (3, 1, 4, 24, 96, 12), (2, 2, 2, 40, 100, 20), (2, 1, 3, 28, 84, 28),
-                                  (3, 2, 9, 3, 12, 3), (2, 2, 2, 6, 12, 6), (37, 2, 4, 33, 44, 11)])
+                                  (3, 2, 9, 3, 12, 3), (2, 2, 2, 6, 12, 6), (37, 2, 4, 33, 44, 11),
+                                  # flat map for any r (LaneMap<3>): block rows cut by wave boundaries (Y = 516: 129 float4
+                                  # per row), a prime r above 16, a block wider than a wave's 256 columns cannot occur
+                                  # (r <= 128) but one of 100 columns spans 26 lanes, r = 128 itself
+                                  (2, 1, 2, 9, 516, 3), (2, 2, 3, 34, 68, 17), (1, 2, 2, 100, 200, 100), (1, 1, 2, 128, 256, 128),
+                                  (3, 1, 5, 21, 252, 7)])
 def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     """Every 5-D kernel against torch float64 formulas on shapes the solver tests cannot reach (X != Y, one wave
     tile, inactive waves in the last workgroup, fewer slabs than workgroups, ragged z-chunks, block rows that wrap inside
-    a wave, a plane smaller than a wave; r = 2, 4, 8, the row-part tile's 16, 32, 64 and - through the general tile - 3, 5, 7
+    a wave, a plane smaller than a wave; r = 2, 4, 8, the row-part tile's 16, 32, 64 (the flat map when Y % 32 != 0) and - through the flat map for any r - every r up to 128
     with Y % 4 == 0 take the fast kernels, everything else the generic ones: float4 lanes when the slab length is a multiple of 4, else scalar)."""
     from datafusion_amd import _cabi as cabi
     from datafusion_amd.kernels import HipKernels
@@ -299,7 +303,7 @@ def test_kernels_on_ragged_and_nonsquare_geometries(dims):
     n_t, n_l, n_z, X, Y, r = dims
     k = HipKernels(n_t, n_l, n_z, X, Y, r, DEV)
     import math
-    assert k.plan.fast == (1 if Y % 4 == 0 and math.lcm(r, 4) <= 64 else 0)       # r = 2, 4, 8; 16, 32, 64; strip tile
+    assert k.plan.fast == (1 if Y % 4 == 0 and 2 <= r <= 128 else 0)       # r = 2, 4, 8; 16, 32, 64; strip tile
     if r in (2, 4, 8, 16, 32, 64) and Y % 32 == 0:
         assert k.v_layers == k.plan.n_zchunks * (r // 4 if r >= 16 else 1)
     x, rr, p = (torch.randn(k.shape, device=DEV) for _ in range(3))

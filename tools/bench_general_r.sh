@@ -1,9 +1,10 @@
 #!/bin/bash
-# Block sizes other than 2, 4, 8 and plane widths that are not multiples of 32, at C2 size: row-part tile (16, 32), strip tile
-# (3, 5, 6, 7, 10, 12), flat map (r = 2, 4, 8 on 120 / 100 / 200-wide planes), generic kernels (Y % 4 != 0, odd slab length).
-# For comparison: DFX_NO_GENERAL_TILE=1 sends the strip-tile sizes to the generic kernels, DFX_NT_ANY_WIDTH=1 keeps
-# r = 4 on the non-temporal row map whatever the width, DFX_NO_FLAT_MAP=1 sends the flat map's shapes to the strip tile,
-# DFX_NO_ROWPART_TILE=1 sends 16 / 32 to the flat map, DFX_FLAT_ANY_WIDTH=1 runs the flat map on aligned rows too.
+# Block sizes other than 2, 4, 8 and plane widths that are not multiples of 32, at C2 size: row-part tile (16, 32), flat map
+# for any r (3, 5, 6, 7, 10, 12), flat map (r = 2, 4, 8 on 120 / 100 / 200-wide planes), generic kernels (Y % 4 != 0, odd
+# slab length).  For comparison: DFX_NO_GENERAL_TILE=1 sends the other block sizes to the generic kernels,
+# DFX_NT_ANY_WIDTH=1 keeps r = 4 on the non-temporal row map whatever the width, DFX_NO_FLAT_MAP=1 sends the power-of-two
+# flat map's shapes to the flat map for any r, DFX_NO_ROWPART_TILE=1 sends 16 / 32 to the flat map, DFX_FLAT_ANY_WIDTH=1
+# runs the flat map on aligned rows too.
 set -o pipefail
 OUT=gpurun_out/general_r_bench.txt; : > $OUT
 line() { python3 tools/_bench_line.py; }
@@ -17,8 +18,8 @@ for W in c2r3 c2r6 c2r12; do
 done
 echo "## DFX_NT_ANY_WIDTH=1 bench.py --workload c2y120 --single --no-cpu --steps 20   (non-temporal r = 4 map on 480-byte rows)" >> $OUT
 DFX_NT_ANY_WIDTH=1 timeout -k 10 200 python3 bench.py --workload c2y120 --single --no-cpu --steps 20 2>/dev/null | line >> $OUT || exit 1
-for W in c2y120 c2y100 c2y200 c2r2y120 c2r8y120; do
-  echo "## DFX_NO_FLAT_MAP=1 bench.py --workload $W --single --no-cpu --steps 20   (strip tile)" >> $OUT
+for W in c2y120 c2y100 c2y200 c2r8y120; do
+  echo "## DFX_NO_FLAT_MAP=1 bench.py --workload $W --single --no-cpu --steps 20   (flat map for any r)" >> $OUT
   DFX_NO_FLAT_MAP=1 timeout -k 10 200 python3 bench.py --workload $W --single --no-cpu --steps 20 2>/dev/null | line >> $OUT || exit 1
 done
 echo "## DFX_FLAT_ANY_WIDTH=1 bench.py --workload c2 --single --no-cpu --steps 20   (flat map on aligned rows)" >> $OUT

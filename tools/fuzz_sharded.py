@@ -35,7 +35,7 @@ def worker(rank, port, cases, seed, q, general_r=False):
         r = rng.choice([3, 5, 6, 7, 10, 12, 16, 16, 32] if general_r else [2, 4, 4, 4, 8, 3])
         xs = rng.randint(1, 48 // r)
         if general_r:
-            xs = 4 * rng.randint(1, max(1, 24 // r))      # Y = xs r a multiple of 4: the general-r tile (LaneMap<0>)
+            xs = 4 * rng.randint(1, max(1, 24 // r))      # Y = xs r a multiple of 4: the strip tile (LaneMap<0>), the flat map for 16 / 32 (Y % 32 != 0 here)
         n_t, n_l = rng.randint(1, 10), rng.randint(1, 6)
         n_z = rng.randint(world, 17)
         xy = xs * r
@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--cases", type=int, default=24)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--port", type=int, default=29671)
-    ap.add_argument("--general-r", action="store_true", help="r in {3, 5, 6, 7, 10, 12, 16} with Y % 4 == 0 only")
+    ap.add_argument("--general-r", action="store_true", help="r in {3, 5, 6, 7, 10, 12, 16, 32} with Y % 4 == 0 only")
     a = ap.parse_args()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -24,10 +24,10 @@ def main():
     rng = random.Random(a.seed)
     worst = 0.0
     for case in range(a.cases):
-        r = rng.choice([2, 4, 4, 4, 8, 3, 3, 5, 6, 7, 9, 10, 12, 16, 16, 32])     # 3, 5, 7: LaneMap<0> when Y % 4 == 0; 16, 32: LaneMap<16>
+        r = rng.choice([2, 4, 4, 4, 8, 3, 3, 5, 6, 7, 9, 10, 12, 16, 16, 32])     # Y % 4 == 0: strip tile (LaneMap<0>) for other r; 16, 32: row-part tile or, Y % 32 != 0, the flat map (as 2, 4, 8 then)
         xs = rng.randint(1, max(2, 96 // r))
         if r not in (2, 4, 8) and rng.random() < 0.6:
-            xs = 4 * ((xs + 3) // 4)                                       # Y = xs r a multiple of 4: the general-r fast path
+            xs = 4 * ((xs + 3) // 4)                                       # Y = xs r a multiple of 4: the fast kernels
         n_t, n_l, n_z = rng.randint(1, 12), rng.randint(1, 7), rng.randint(1, 19)
         xy = xs * r
         w = {"spatial": rng.choice([0.5, 0.2, 0.8]), "spectro_temporal": rng.choice([0.5, 0.8, 0.2])}
