@@ -39,11 +39,11 @@ typedef struct dfx_geom {
 } dfx_geom;
 
 /* Launch plan + workspace sizes for one geometry.  fast=1: float4 wave-tile kernels
- * (Y % 4 == 0 and lcm(r, 4) <= 64: r in {2, 4, 8}, the row-part tile's {16, 32, 64}, a strip tile for other r;
+ * (Y % 4 == 0 and 2 <= r <= 128: row maps for r in {2, 4, 8}, a row-part tile for {16, 32, 64}, flat maps otherwise;
  * small-space rows B / v_part 8-byte aligned when r = 2); fast=0: shape-generic kernels (any r, any Y).
  * v_part holds LAYERS of nT*nL*Xs*Ys floats that dfx_post_sweep / dfx_reduce_v add up: one per z-chunk, times a
- * factor of the lane map (r / 4 for r in {16, 32, 64}; r for a power-of-two r on planes with Y % 32 != 0; the 4-row
- * strips a block row meets for other r); layers = v_part_elems / (nT*nL*Xs*Ys).  With ONE layer v_part is v itself. */
+ * factor of the lane map (r / 4 for r in {16, 32, 64}; r for a power-of-two r on planes with Y % 32 != 0; 2 r for
+ * other r); layers = v_part_elems / (nT*nL*Xs*Ys).  With ONE layer v_part is v itself. */
 typedef struct dfx_plan {
     int32_t fast;
     int32_t zc;          /* z planes a workgroup keeps in registers */
