@@ -2293,14 +2293,10 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
             const int n = (q.nZ + zc - 1) / zc;
             zs = (q.nZ + n - 1) / n;
         }
-        out->zc = zc;
-        out->zs = zs;
-        out->n_zchunks = (q.nZ + zs - 1) / zs;
         // Grid sizing.  Measured on MI355X (tools/tune_kernels.py): these kernels stream fastest with ONE
         // 4-wave workgroup per CU walking a long run of slabs (C2: 6.0 TB/s at 256 workgroups vs 5.5 at 2048:
         // fewer concurrent DRAM streams), so the default target is the CU count.  `steps` only sets how often
         // the fp32 u accumulators are flushed to u_part (accuracy + 2N/steps words of extra traffic).
-        const long long groups = (long long)((q.WT + DFX_WAVES - 1) / DFX_WAVES) * out->n_zchunks;
         long long steps = steps_req > 0 ? steps_req : 64;
         if (steps > q.M) steps = q.M;
         long long n_chunks = (q.M + steps - 1) / steps;
@@ -2312,10 +2308,12 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
             (void)hipGetLastError();
             target_blocks = cus;
         }
-        // workgroups along the slab axis: fill whole "rounds" of one workgroup per CU (80 tile groups on 256 CUs:
-        // gz = 3 or 6 -> 240 / 480 workgroups, not 4 -> 320, which leaves a quarter-full second round)
-        long long gz = 1;
-        {
+        const long long tile_groups = (q.WT + DFX_WAVES - 1) / DFX_WAVES;
+        // workgroups along the slab axis for `nzc` z-chunks: fill whole "rounds" of one workgroup per CU (80 tile groups
+        // on 256 CUs: gz = 3 or 6 -> 240 / 480 workgroups, not 4 -> 320, which leaves a quarter-full second round)
+        auto pick_gz = [&](long long nzc, double *score_out) {
+            const long long groups = tile_groups * nzc;
+            long long gz = 1;
             double best = -1.0;
             const long long gz_hi = (4LL * target_blocks + groups - 1) / groups;
             for (long long c = 1; c <= gz_hi && c <= n_chunks && c <= 65535; ++c) {
@@ -2325,7 +2323,24 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
                 const double score = (double)nb / (double)(rounds * target_blocks) - 0.06 * (double)(rounds - 1);
                 if (score > best + 1e-9) best = score, gz = c;
             }
+            if (score_out) *score_out = best;
+            return gz;
+        };
+        double fill = 0.0;
+        long long gz = pick_gz((q.nZ + zs - 1) / zs, &fill);
+        // Filling idle CUs with another number of z-chunks does not pay: t64 x l16 x z20 x 128^2 as 16 tile groups x 4
+        // chunks of 5 planes = 256 workgroups ran 0.939 ms against 0.876 ms as 5 chunks of 4 planes = 240 workgroups
+        // (DFX_PLAN_ZS=5, a measurement knob: planes per z-chunk).
+        static const int zs_env = [] { const char *e = getenv("DFX_PLAN_ZS"); return e ? atoi(e) : 0; }();
+        if (!zc_req && zs_env >= 1 && zs_env <= 8) {
+            zs = zs_env < q.nZ ? zs_env : q.nZ;
+            zc = zs <= 4 ? 4 : 8;
+            gz = pick_gz((q.nZ + zs - 1) / zs, &fill);
         }
+        out->zc = zc;
+        out->zs = zs;
+        out->n_zchunks = (q.nZ + zs - 1) / zs;
+        const long long groups = tile_groups * out->n_zchunks;
         long long cpb = (n_chunks + gz - 1) / gz;
         gz = (n_chunks + cpb - 1) / cpb;
         n_chunks = cpb * gz;   // with interleaving the last chunks may cover fewer (or no) slabs
