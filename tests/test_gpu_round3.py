@@ -245,6 +245,19 @@ def test_bench_starts_its_own_ranks():
         assert "needs 2 GPUs, found 1" in p.stderr
 
 
+@pytest.mark.parametrize("shape,r", [("256,16,16,120", 4), ("256,16,16,120", 3), ("256,16,16,128", 16), ("256,16,16,100", 2)])
+def test_lane_maps_at_bench_size_vs_fp64_collapsed_cg(shape, r):
+    """Every lane map beside r = 4's row map at the size bench.py measures it (about 2^30 elements; offsets beyond 2^31
+    bytes, hundreds of workgroups, thousands of slabs per workgroup): the flat map (r = 4 and r = 2 on planes whose rows are
+    not 128-byte aligned), the flat map for any r (r = 3) and the row-part tile (r = 16); 10 CG iterations against the fp64
+    collapsed CG, north_star's 1e-4 asserted by the tool, ~8e-8 measured (profiles/r03_verify_lane_maps.txt)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "verify_large.py"), "--shape", shape, "--r", str(r)],
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["fast"] == 1 and out["rel_l2_vs_fp64_collapsed"] <= 1e-6, out
+
+
 def test_bench_two_rank_control_flow_rehearsal():
     """The N > 1 control flow of bench.py with TWO real processes: self-launch, the strong-scaling leg (rank 0 runs the
     one-GPU anchor first while rank 1 waits at the barrier, then both run their halves), the weak-scaled headline, the

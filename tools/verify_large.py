@@ -24,9 +24,10 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--residual", default="factored", choices=["factored", "explicit"])
     ap.add_argument("--cells", action="store_true", help="cells-like inputs (blobs x decays x spectra) instead of uniform")
+    ap.add_argument("--r", type=int, default=4, help="spatial_increase (other lane maps: 16 row-part tile, 3 flat map for any r ...)")
     a = ap.parse_args()
     n_t, n_l, n_z, xy = map(int, a.shape.split(","))
-    r, dev = 4, "cuda:0"
+    r, dev = a.r, "cuda:0"
     w = {"spatial": 0.5, "spectro_temporal": 0.5}
     spc, cmos = (O.cells_like_inputs if a.cells else O.synthetic_inputs)(n_t, n_l, n_z, xy, r)
     t0 = time.time()
@@ -56,7 +57,7 @@ def main():
         num += ((x[t].double() - ref) ** 2).sum()
         den += (ref ** 2).sum()
     err = float(torch.sqrt(num / den))
-    out = {"shape": [n_t, n_l, n_z, xy, xy], "n_elements": f.k.N, "iterations": a.iters, "residual": a.residual,
+    out = {"shape": [n_t, n_l, n_z, xy, xy], "r": r, "fast": int(f.k.plan.fast), "v_layers": int(f.k.v_layers), "n_elements": f.k.N, "iterations": a.iters, "residual": a.residual,
            "inputs": "cells-like" if a.cells else "uniform",
            "rel_l2_vs_fp64_collapsed": err, "rsnew_gpu": rs_gpu, "rsnew_fp64": rs[-1], "alpha_last_fp64": alphas[-1],
            "alpha_last_gpu": float(f.k.scal[24])}
