@@ -48,6 +48,8 @@ WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "c2r16": (256, 16, 16, 128, 16),     # row-part tile (LaneMap<16>: r = 16, 32, 64)
     "c2r32": (256, 16, 16, 128, 32),
     "c2y120": (256, 16, 16, 120, 4),     # r = 4 on planes whose rows are not 128-byte aligned (480 B pitch)
+    "c2y96": (256, 16, 16, 96, 4),       # 128-byte aligned rows that are not multiples of a wave tile's 64 columns (row maps)
+    "c2y160": (128, 16, 16, 160, 4),
     "c2y100": (256, 16, 24, 100, 4),     # ... not 32-byte aligned either (Y % 8 != 0)
     "c2y200": (128, 16, 13, 200, 4),
     "c2r2y120": (256, 16, 16, 120, 2),
@@ -59,6 +61,11 @@ WORKLOADS = {  # per-GPU slab: (nT, nL, nZ per GPU, XY, r)
     "p512s": (16, 4, 16, 512, 4),        # wide planes (more workgroups than CUs) with few / many slabs per workgroup
     "p512m": (64, 16, 16, 512, 4),
     "p1k": (4, 2, 8, 1024, 4),
+    "f128m1k": (64, 16, 16, 128, 4),     # neighbours of C2 (planner experiments: planes per z-chunk, tools/exp_zs.sh)
+    "f128z8": (256, 16, 8, 128, 4),
+    "f128z32": (256, 16, 32, 128, 4),
+    "f64z16": (1024, 16, 16, 64, 4),
+    "f256z16": (64, 16, 16, 256, 4),
     "tiny": (8, 4, 4, 64, 4),
 }
 

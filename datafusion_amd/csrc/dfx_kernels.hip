@@ -2328,6 +2328,18 @@ int dfx_plan_make_ex(const dfx_geom *g, int32_t target_blocks, int32_t zc_req, i
         };
         double fill = 0.0;
         long long gz = pick_gz((q.nZ + zs - 1) / zs, &fill);
+        // Planes of at most 16 tile groups (128 x 128 and smaller) on the row maps stream faster in z-chunks of TWO planes
+        // whenever those still fill the chip in one round: more z-chunks mean fewer slab lanes (gz 8 -> 2 at C2), i.e. a
+        // tighter window of concurrently streamed slabs.  Measured (tools/exp_zs.sh, sweep of the factored iteration,
+        // 8 -> 2 planes): t256 x l16 x z16 x 128^2 2.696 -> 2.629 ms (r = 8: 2.719 -> 2.661, r = 16: 2.701 -> 2.630),
+        // t64 x l16 x z16 x 128^2 0.717 -> 0.671, z8 1.362 -> 1.311, t1024 x l16 x z16 x 64^2 3.323 -> 3.052, z32 x 128^2
+        // 5.348 -> 5.362; the fused Adam step 2.703 -> 2.644.  NOT for larger planes (256^2 x z16 at t512 x l32: 43.2 ->
+        // 45.3 ms with 4 planes), r = 2 (2.727 -> 2.743) or the flat maps (120^2: 3.005 -> 3.865 ms).
+        if (!zc_req && (q.lm == 4 || q.lm == 8 || q.lm == 16) && tile_groups <= 16 && zs > 2 && q.nZ % 2 == 0 && fill >= 0.99) {
+            double f2 = 0.0;
+            const long long gz2 = pick_gz(q.nZ / 2, &f2);
+            if (f2 >= 0.99 && tile_groups * (q.nZ / 2) * gz2 <= target_blocks) zc = 4, zs = 2, gz = gz2, fill = f2;
+        }
         // Filling idle CUs with another number of z-chunks does not pay: t64 x l16 x z20 x 128^2 as 16 tile groups x 4
         // chunks of 5 planes = 256 workgroups ran 0.939 ms against 0.876 ms as 5 chunks of 4 planes = 240 workgroups
         // (DFX_PLAN_ZS=5, a measurement knob: planes per z-chunk).

@@ -51,8 +51,9 @@ doc = {"workload": "c2",
        "correction": "MI355X_MICROARCH.md HBM section: counters are KiB; on gfx950 FETCH_SIZE reports 1/2 of a 16 B/lane "
                      "coalesced streaming read -> doubled; WRITE_SIZE exact",
        "kernels": out,
-       "algorithmic_bytes": {"k_sweep_fast<XP,8,r4,factored>": 16 * N, "k_sweep_fast<XP,8,r4,explicit>": 20 * N,
-                             "k_bcast_fast<8, 4, true, false>": 8 * N, "k_adam_fast<8, 4, false, true>": 16 * N}}
+       "algorithmic_bytes": {f"k_sweep_fast<XP,{zc},r4,{res}>": w * N for zc in (4, 8) for res, w in (("factored", 16), ("explicit", 20))}}
+doc["algorithmic_bytes"].update({f"k_bcast_fast<{zc}, 4, true, false>": 8 * N for zc in (4, 8)})
+doc["algorithmic_bytes"].update({f"k_adam_fast<{zc}, 4, false, true, false>": 16 * N for zc in (4, 8)})
 for k, b in doc["algorithmic_bytes"].items():
     if k in out:
         out[k]["traffic_over_algorithmic"] = out[k]["traffic_bytes"] / b
