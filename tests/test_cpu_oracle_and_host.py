@@ -430,6 +430,20 @@ def test_planner_balances_z_chunks(n_z, expect):
     assert (p.zc, p.zs, p.n_zchunks) == expect
 
 
+@pytest.mark.parametrize("dims,expect", [((256, 16, 16, 128, 128, 4), (4, 2, 8, 256)), ((256, 16, 16, 128, 128, 16), (4, 2, 8, 256)),
+                                         ((256, 16, 16, 128, 128, 2), (8, 8, 2, 256)), ((64, 16, 20, 128, 128, 4), (4, 4, 5, 240)),
+                                         ((512, 32, 32, 256, 256, 4), (8, 8, 4, 256)), ((256, 16, 32, 512, 512, 4), (8, 8, 4, 1024)),
+                                         ((512, 32, 4, 256, 256, 4), (4, 4, 1, 256)), ((256, 16, 16, 120, 120, 4), (8, 8, 2, 240))])
+def test_planner_at_bench_sizes(dims, expect):
+    """(zc, zs, n_zchunks, workgroups) on a 256-CU device for the shapes bench.py measures: z-chunks of two planes where
+    they were measured to win (row maps r = 4, 8, 16 on planes of at most 16 tile groups, the chip still filled in one
+    round: DESIGN.md section 4, profiles/r03_planes_per_zchunk.txt) and the padding-minimal chunking everywhere else."""
+    from datafusion_amd import _cabi as cabi
+    g, p = cabi.Geom(*dims, 0), cabi.Plan()
+    assert cabi.lib().dfx_plan_make(C.byref(g), 256, C.byref(p)) == 0
+    assert (p.zc, p.zs, p.n_zchunks, p.n_blocks) == expect
+
+
 def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     """include/dfx.h must be usable from C (the drop-in boundary is a C ABI): compile a C99 program against it with
     -pedantic, link libdfx.so, run the host-only planner."""
