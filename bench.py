@@ -219,9 +219,26 @@ def bench_adam(a, world, rank, dev, group, use_dist):
         name, words = ("adamf", 4) if fact else ("adam", 6)       # x, m2 (and m1) read + written
         ach = 4.0 * words * n_local / (kern[name] * 1e-3) / 1e9
         out["config"]["moment1"] = a.moment1
+        traffic, t_src = None, "none: PMC passes exist for the factored first moment on the c2 workload, one GPU, no mask"
+        if fact and a.workload == "c2" and world == 1:
+            # the PMC record of tools/profile_all.sh (its `--method adam` passes), replayed under the same conditions as
+            # the CG line's: same kernel source (sha256), same workload
+            import hashlib
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_RECORD)))
+                src = hashlib.sha256(open(os.path.join(ROOT, "datafusion_amd", "csrc", "dfx_kernels.hip"), "rb").read()).hexdigest()
+                if pmc.get("kernel_source_sha256") == src and pmc["workload"] == a.workload:
+                    traffic = pmc["kernels"][f"k_adam_fast<{f.k.plan.zc}, {r}, false, true, false>"]["traffic_bytes"]
+                    t_src = (f"replayed from profiles/{PMC_RECORD} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                             f"command on this kernel source, sha256 {src[:12]}; FETCH_SIZE doubled per MI355X_MICROARCH.md): "
+                             "not a measurement of this run")
+                else:
+                    t_src = f"none: profiles/{PMC_RECORD} was taken on another build of dfx_kernels.hip"
+            except (OSError, KeyError, ValueError) as e:
+                t_src = f"none: {type(e).__name__} reading profiles/{PMC_RECORD}"
         out["roofline"] = {"bound": "hbm", "kernel": f"k_adam_fast<{f.k.plan.zc},{a.moment1} m1>", "achieved": ach,
-                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                           "bytes_per_launch": 4 * words * n_local, "avg_launch_ms": kern[name]}
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                           "traffic_source": t_src, "bytes_per_launch": 4 * words * n_local, "avg_launch_ms": kern[name]}
     if rank == 0:
         emit(out)
     if use_dist:
